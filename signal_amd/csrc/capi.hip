@@ -1,0 +1,94 @@
+// extern "C" surface of libsignal_hip.so (declared in include/signal_hip.h).
+#include <stdarg.h>
+
+#include "../../include/signal_hip.h"
+#include "sig_common.h"
+#include "sig_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void sig_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static_assert(SIG_GEMM_F32 == SIG_EPI_F32 && SIG_GEMM_BF16 == SIG_EPI_BF16 && SIG_GEMM_BIAS_F32 == SIG_EPI_BIAS_F32 &&
+                  SIG_GEMM_BIAS_BF16 == SIG_EPI_BIAS_BF16 && SIG_GEMM_BIAS_RES_F32 == SIG_EPI_BIAS_RES_F32 &&
+                  SIG_GEMM_BIAS_GELU_BF16 == SIG_EPI_BIAS_GELU_BF16 && SIG_GEMM_DGELU_BF16 == SIG_EPI_DGELU_BF16,
+              "public and internal epilogue ids must agree");
+
+extern "C" {
+
+const char* sig_last_error(void) { return g_err; }
+int sig_version(void) { return SIG_ABI_VERSION; }
+
+int sig_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, int epilogue, void* out,
+                int ldo, const float* bias, const float* res, int ldr, void* aux, int ldaux, void* stream) {
+    SigGemmNT p;
+    p.A = A; p.Bt = Bt; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
+    p.out = out; p.ldo = ldo; p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
+    return sig_launch_gemm_nt(p, epilogue, (hipStream_t)stream);
+}
+
+int sig_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, int Mr, int I, int J, float* out, int ldo,
+                int split, void* stream) {
+    SigGemmTN p;
+    p.P = P; p.Q = Q; p.ldp = ldp; p.ldq = ldq; p.Mr = Mr; p.I = I; p.J = J; p.out = out; p.ldo = ldo;
+    p.split = split; p.m_chunk = 0;
+    return sig_launch_gemm_tn(p, (hipStream_t)stream);
+}
+
+int sig_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y_bf16, float* y_f32, float* mean,
+                      float* rstd, int M, int D, float eps, void* stream) {
+    return sig_launch_layernorm_fwd(x, gamma, beta, y_bf16, y_f32, mean, rstd, M, D, eps, (hipStream_t)stream);
+}
+
+int sig_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, const float* dres, float* dx_f32, uint16_t* dx_bf16, float* dgamma, float* dbeta,
+                      int M, int D, void* stream) {
+    return sig_launch_layernorm_bwd(dy, dy_is_bf16, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D,
+                                    (hipStream_t)stream);
+}
+
+int sig_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int S, int L, int H, void* stream) {
+    return sig_launch_attn_fwd(qkv, out, lse, S, L, H, (hipStream_t)stream);
+}
+
+int sig_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, uint16_t* dqkv, int S,
+                 int L, int H, void* stream) {
+    return sig_launch_attn_bwd(qkv, out, dout, lse, dqkv, S, L, H, (hipStream_t)stream);
+}
+
+int sig_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
+    return sig_launch_cast_bf16(src, dst, n, (hipStream_t)stream);
+}
+int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, void* stream) {
+    return sig_launch_transpose_cast_bf16(src, dst, rows, cols, (hipStream_t)stream);
+}
+int sig_colsum_bf16(const uint16_t* a, int lda, int M, int N, float* out, void* stream) {
+    return sig_launch_colsum_bf16(a, lda, M, N, out, (hipStream_t)stream);
+}
+int sig_colsum_f32(const float* a, int lda, int M, int N, float* out, void* stream) {
+    return sig_launch_colsum_f32(a, lda, M, N, out, (hipStream_t)stream);
+}
+
+int sig_im2col(const float* img, uint16_t* out, int nimg, int H, int W, int P, void* stream) {
+    return sig_launch_im2col(img, out, nimg, H, W, P, (hipStream_t)stream);
+}
+int sig_embed_assemble(const float* tok, const float* class_embedding, const float* positional_embedding,
+                       const float* cv_embed, const int64_t* cam_label, float sie_coe, const float* ln_w,
+                       const float* ln_b, float* x, float* pre_ln, float* mean, float* rstd, int S, int B, int L, int D,
+                       float eps, void* stream) {
+    return sig_launch_embed_assemble(tok, class_embedding, positional_embedding, cv_embed, cam_label, sie_coe, ln_w, ln_b,
+                                     x, pre_ln, mean, rstd, S, B, L, D, eps, (hipStream_t)stream);
+}
+int sig_embed_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dtok_bf16, float* d_class_embedding,
+                  float* d_positional_embedding, float* d_cv_embed, const int64_t* cam_label, float sie_coe, int S, int B,
+                  int L, int D, void* stream) {
+    return sig_launch_embed_bwd(d_pre_ln, dtok_f32, dtok_bf16, d_class_embedding, d_positional_embedding, d_cv_embed,
+                                cam_label, sie_coe, S, B, L, D, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,402 @@
+// Row-wise, HBM-bound kernels around the contractions: LayerNorm fwd/bwd, weight packing (f32 -> bf16,
+// optional transpose), patch gather (im2col), token assembly (+CLS, camera, positional, ln_pre) and its
+// backward, column sums (bias gradients).  One wavefront per token row, 16-B accesses, shuffle reductions.
+#include "sig_common.h"
+#include "sig_kernels.h"
+
+#define LN_MAXV 4  // float4 per lane -> D <= 1024
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward: x f32 [M,D] -> y (bf16 and/or f32), mean/rstd [M]      (clip/model.py:154-160)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ yb,
+                                                            float* __restrict__ yf, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            v[it] = *(const float4*)(xr + c);
+            s += v[it].x + v[it].y + v[it].z + v[it].w;
+        }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float a = v[it].x - mu, b = v[it].y - mu, cc = v[it].z - mu, d = v[it].w - mu;
+            q += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            float4 o;
+            o.x = (v[it].x - mu) * rs * g.x + b.x;
+            o.y = (v[it].y - mu) * rs * g.y + b.y;
+            o.z = (v[it].z - mu) * rs * g.z + b.z;
+            o.w = (v[it].w - mu) * rs * g.w + b.w;
+            if (yf) *(float4*)(yf + (size_t)row * D + c) = o;
+            if (yb) *(uint2*)(yb + (size_t)row * D + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+        }
+    }
+}
+
+int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y_bf16, float* y_f32,
+                             float* mean, float* rstd, int M, int D, float eps, hipStream_t st) {
+    SIG_CHECK_ARG(M > 0 && D > 0 && (D & 3) == 0 && D <= 256 * LN_MAXV, "layernorm_fwd: D=%d unsupported (multiple of 4, <= 1024)", D);
+    SIG_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(sig_ceil_div(M, 4)), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32,
+                       mean, rstd, M, D, eps);
+    SIG_CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  dx = dres + rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));
+// dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (register partials per wave, LDS across the 4 waves,
+// one atomic per column per workgroup).
+// ------------------------------------------------------------------------------------------------
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                            float* __restrict__ dxf, bf16_t* __restrict__ dxb,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
+    __shared__ float red[2][4][256 * LN_MAXV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 g[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        g[it] = c < D ? *(const float4*)(gamma + c) : make_float4(0, 0, 0, 0);
+        ag[it] = make_float4(0, 0, 0, 0);
+        ab[it] = make_float4(0, 0, 0, 0);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 dyv[LN_MAXV], xh[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < LN_MAXV; ++it) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                if (DY_BF16) {
+                    const uint2 u = *(const uint2*)((const bf16_t*)dy_ + (size_t)row * D + c);
+                    dyv[it] = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)),
+                                          bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+                } else {
+                    dyv[it] = *(const float4*)((const float*)dy_ + (size_t)row * D + c);
+                }
+                const float4 xv = *(const float4*)(x + (size_t)row * D + c);
+                xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                const float a0 = dyv[it].x * g[it].x, a1 = dyv[it].y * g[it].y, a2 = dyv[it].z * g[it].z, a3 = dyv[it].w * g[it].w;
+                s1 += a0 + a1 + a2 + a3;
+                s2 += a0 * xh[it].x + a1 * xh[it].y + a2 * xh[it].z + a3 * xh[it].w;
+                ag[it].x += dyv[it].x * xh[it].x; ag[it].y += dyv[it].y * xh[it].y;
+                ag[it].z += dyv[it].z * xh[it].z; ag[it].w += dyv[it].w * xh[it].w;
+                ab[it].x += dyv[it].x; ab[it].y += dyv[it].y; ab[it].z += dyv[it].z; ab[it].w += dyv[it].w;
+            }
+        }
+        const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int it = 0; it < LN_MAXV; ++it) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                float4 o;
+                o.x = rs * (dyv[it].x * g[it].x - m1 - xh[it].x * m2);
+                o.y = rs * (dyv[it].y * g[it].y - m1 - xh[it].y * m2);
+                o.z = rs * (dyv[it].z * g[it].z - m1 - xh[it].z * m2);
+                o.w = rs * (dyv[it].w * g[it].w - m1 - xh[it].w * m2);
+                if (dres) {
+                    const float4 r = *(const float4*)(dres + (size_t)row * D + c);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                if (dxf) *(float4*)(dxf + (size_t)row * D + c) = o;
+                if (dxb) *(uint2*)(dxb + (size_t)row * D + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+            }
+        }
+    }
+    if (!dgamma) return;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        *(float4*)&red[0][wave][c] = ag[it];
+        *(float4*)&red[1][wave][c] = ab[it];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
+                             const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma,
+                             float* dbeta, int M, int D, hipStream_t st) {
+    SIG_CHECK_ARG(M > 0 && D > 0 && (D & 3) == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D=%d unsupported", D);
+    SIG_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
+    SIG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
+    int blocks = sig_ceil_div(M, 4);
+    if (blocks > 1024) blocks = 1024;
+    if (dy_is_bf16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres,
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres,
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D);
+    SIG_CHECK_LAUNCH("layernorm_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256 * 8;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const float4 a = *(const float4*)(src + i), b = *(const float4*)(src + i + 4);
+            *(uint4*)(dst + i) = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+        } else {
+            for (size_t k = i; k < n; ++k) dst[k] = f2bf(src[k]);
+        }
+    }
+}
+int sig_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st) {
+    SIG_CHECK_ARG(src && dst && n > 0, "cast_bf16: bad arguments");
+    SIG_CHECK_ARG((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, "cast_bf16: pointers must be 16-B aligned");
+    size_t blocks = (n + 2047) / 2048;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
+    SIG_CHECK_LAUNCH("cast_bf16");
+    return 0;
+}
+
+// dst[c][r] = bf16(src[r][c]);  64x64 tile through LDS (65-float rows: conflict-free column reads)
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4)
+        tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(size_t)(r0 + r) * cols + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (c0 + c < cols && r0 + tx < rows) dst[(size_t)(c0 + c) * rows + r0 + tx] = f2bf(tile[tx][c]);
+}
+int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st) {
+    SIG_CHECK_ARG(src && dst && rows > 0 && cols > 0, "transpose_cast: bad arguments");
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3(sig_ceil_div(cols, 64), sig_ceil_div(rows, 64)), dim3(256), 0, st, src, dst, rows, cols);
+    SIG_CHECK_LAUNCH("transpose_cast");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (bias gradients): out[n] += sum_m a[m][n]
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ a_, int lda, int M, int N, float* __restrict__ out) {
+    constexpr int CPL = BF16 ? 8 : 4;  // columns per lane (16 B)
+    __shared__ float red[4][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.y * 64 + lane) * CPL;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int rbeg = blockIdx.x * 128 + wave * 32;
+    if (c < N) {
+        for (int r = rbeg; r < rbeg + 32 && r < M; ++r) {
+            if (BF16) {
+                const uint4 u = *(const uint4*)((const bf16_t*)a_ + (size_t)r * lda + c);
+                acc[0] += bf2f((bf16_t)(u.x & 0xffff)); acc[1] += bf2f((bf16_t)(u.x >> 16));
+                acc[2] += bf2f((bf16_t)(u.y & 0xffff)); acc[3] += bf2f((bf16_t)(u.y >> 16));
+                acc[4] += bf2f((bf16_t)(u.z & 0xffff)); acc[5] += bf2f((bf16_t)(u.z >> 16));
+                acc[6] += bf2f((bf16_t)(u.w & 0xffff)); acc[7] += bf2f((bf16_t)(u.w >> 16));
+            } else {
+                const float4 v = *(const float4*)((const float*)a_ + (size_t)r * lda + c);
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) red[wave][lane * CPL + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * CPL; i += 256) {
+        const int col = blockIdx.y * 64 * CPL + i;
+        if (col < N) atomicAdd(out + col, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+    }
+}
+int sig_launch_colsum_bf16(const bf16_t* a, int lda, int M, int N, float* out, hipStream_t st) {
+    SIG_CHECK_ARG(a && out && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0, "colsum_bf16: N and lda must be multiples of 8");
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3(sig_ceil_div(M, 128), sig_ceil_div(N, 512)), dim3(256), 0, st, a, lda, M, N, out);
+    SIG_CHECK_LAUNCH("colsum_bf16");
+    return 0;
+}
+int sig_launch_colsum_f32(const float* a, int lda, int M, int N, float* out, hipStream_t st) {
+    SIG_CHECK_ARG(a && out && M > 0 && N > 0 && (N & 3) == 0 && (lda & 3) == 0, "colsum_f32: N and lda must be multiples of 4");
+    hipLaunchKernelGGL(colsum_kernel<false>, dim3(sig_ceil_div(M, 128), sig_ceil_div(N, 256)), dim3(256), 0, st, a, lda, M, N, out);
+    SIG_CHECK_LAUNCH("colsum_f32");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// patch gather: img f32 [nimg,3,H,W] -> bf16 [nimg*h*w, 3*P*P], column = c*P*P + dy*P + dx
+// (the im2col of the stride-16 conv at clip/model.py:433,448-450).  Thread = 8 consecutive pixels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int nimg, int H, int W, int P) {
+    const int w8 = W >> 3;
+    const size_t total = (size_t)nimg * 3 * H * w8;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int x8 = (int)(t % w8);
+        size_t r = t / w8;
+        const int y = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % 3);
+        const int n = (int)(r / 3);
+        const float* src = img + (((size_t)n * 3 + c) * H + y) * W + x8 * 8;
+        const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+        const int x = x8 * 8, pi = y / P, pj = x / P, dy = y - pi * P, dx = x - pj * P;
+        const int wg = W / P, hg = H / P;
+        const size_t row = ((size_t)n * hg + pi) * wg + pj;
+        bf16_t* dst = out + row * (size_t)(3 * P * P) + c * P * P + dy * P + dx;
+        *(uint4*)dst = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+    }
+}
+int sig_launch_im2col(const float* img, bf16_t* out, int nimg, int H, int W, int P, hipStream_t st) {
+    SIG_CHECK_ARG(img && out && nimg > 0, "im2col: bad arguments");
+    SIG_CHECK_ARG(P % 8 == 0 && H % P == 0 && W % P == 0, "im2col: patch %d must be a multiple of 8 and divide %dx%d", P, H, W);
+    const size_t total = (size_t)nimg * 3 * H * (W >> 3);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, out, nimg, H, W, P);
+    SIG_CHECK_LAUNCH("im2col");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// token assembly + ln_pre (clip/model.py:451-459): sequences s = modality*B + b, row 0 = CLS.
+//   pre[s,0]   = class_embedding + sie_coe*cv_embed[cam[b]] + pos[0]
+//   pre[s,1+p] = tok[s*Lp + p] + pos[1+p]
+//   x = LN(pre)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_assemble_kernel(const float* __restrict__ tok, const float* __restrict__ cls_emb,
+                                                             const float* __restrict__ pos, const float* __restrict__ cv,
+                                                             const int64_t* __restrict__ cam, float sie, const float* __restrict__ g,
+                                                             const float* __restrict__ b, float* __restrict__ x, float* __restrict__ pre,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, int S, int B, int L,
+                                                             int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= S * L) return;
+    const int s = row / L, l = row - s * L;
+    float4 v[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            float4 t;
+            if (l == 0) {
+                t = *(const float4*)(cls_emb + c);
+                if (cv) {
+                    const float4 e = *(const float4*)(cv + (size_t)cam[s % B] * D + c);
+                    t.x += sie * e.x; t.y += sie * e.y; t.z += sie * e.z; t.w += sie * e.w;
+                }
+            } else {
+                t = *(const float4*)(tok + ((size_t)s * (L - 1) + (l - 1)) * D + c);
+            }
+            const float4 pe = *(const float4*)(pos + (size_t)l * D + c);
+            t.x += pe.x; t.y += pe.y; t.z += pe.z; t.w += pe.w;
+            v[it] = t;
+            sum += t.x + t.y + t.z + t.w;
+            if (pre) *(float4*)(pre + (size_t)row * D + c) = t;
+        }
+    }
+    const float mu = wave_sum(sum) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float a0 = v[it].x - mu, a1 = v[it].y - mu, a2 = v[it].z - mu, a3 = v[it].w - mu;
+            q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float4 gg = *(const float4*)(g + c), bb = *(const float4*)(b + c);
+            float4 o;
+            o.x = (v[it].x - mu) * rs * gg.x + bb.x;
+            o.y = (v[it].y - mu) * rs * gg.y + bb.y;
+            o.z = (v[it].z - mu) * rs * gg.z + bb.z;
+            o.w = (v[it].w - mu) * rs * gg.w + bb.w;
+            *(float4*)(x + (size_t)row * D + c) = o;
+        }
+    }
+}
+int sig_launch_embed_assemble(const float* tok, const float* cls_emb, const float* pos, const float* cv_embed,
+                              const int64_t* cam, float sie_coe, const float* g, const float* b, float* x,
+                              float* pre_ln, float* mean, float* rstd, int S, int B, int L, int D, float eps,
+                              hipStream_t st) {
+    SIG_CHECK_ARG(tok && cls_emb && pos && g && b && x, "embed_assemble: null pointer");
+    SIG_CHECK_ARG((cv_embed == nullptr) || cam, "embed_assemble: cam labels missing");
+    SIG_CHECK_ARG(S > 0 && B > 0 && S % B == 0 && L > 1 && (D & 3) == 0 && D <= 256 * LN_MAXV, "embed_assemble: bad shape");
+    hipLaunchKernelGGL(embed_assemble_kernel, dim3(sig_ceil_div(S * L, 4)), dim3(256), 0, st, tok, cls_emb, pos, cv_embed,
+                       cam, sie_coe, g, b, x, pre_ln, mean, rstd, S, B, L, D, eps);
+    SIG_CHECK_LAUNCH("embed_assemble");
+    return 0;
+}
+
+// backward of the assembly (given d pre-LN tokens): dtok (f32 and/or bf16, [S*Lp, D]), dpos[l] = sum_s,
+// dcls = sum_s d[s,0], dcv[cam] += sie * d[s,0].  One workgroup column-slab per token position.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dpre, float* __restrict__ dtokf, bf16_t* __restrict__ dtokb,
+                                                        float* __restrict__ dcls, float* __restrict__ dpos, float* __restrict__ dcv,
+                                                        const int64_t* __restrict__ cam, float sie, int S, int B, int L, int D) {
+    const int l = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= D) return;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float v = dpre[((size_t)s * L + l) * D + c];
+        acc += v;
+        if (l == 0) {
+            if (dcv) atomicAdd(dcv + (size_t)cam[s % B] * D + c, sie * v);
+        } else {
+            const size_t o = ((size_t)s * (L - 1) + (l - 1)) * D + c;
+            if (dtokf) dtokf[o] = v;
+            if (dtokb) dtokb[o] = f2bf(v);
+        }
+    }
+    atomicAdd(dpos + (size_t)l * D + c, acc);
+    if (l == 0) atomicAdd(dcls + c, acc);
+}
+int sig_launch_embed_bwd(const float* dx_pre, float* dtok_f32, bf16_t* dtok_bf16, float* dcls, float* dpos,
+                         float* dcv, const int64_t* cam, float sie_coe, int S, int B, int L, int D, hipStream_t st) {
+    SIG_CHECK_ARG(dx_pre && dcls && dpos && (dtok_f32 || dtok_bf16), "embed_bwd: null pointer");
+    SIG_CHECK_ARG((dcv == nullptr) || cam, "embed_bwd: cam labels missing");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(L, sig_ceil_div(D, 256)), dim3(256), 0, st, dx_pre, dtok_f32, dtok_bf16, dcls,
+                       dpos, dcv, cam, sie_coe, S, B, L, D);
+    SIG_CHECK_LAUNCH("embed_bwd");
+    return 0;
+}

@@ -1,0 +1,74 @@
+// Shared device/host helpers for the Signal hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all bf16 tensors cross the C ABI as uint16_t*
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define SIG_WAVE 64
+
+// ---- error plumbing (C ABI returns int, message via sig_last_error) -------------------------
+void sig_set_error(const char* fmt, ...);
+#define SIG_CHECK_ARG(cond, ...)                  \
+    do {                                          \
+        if (!(cond)) {                            \
+            sig_set_error(__VA_ARGS__);           \
+            return 1;                             \
+        }                                         \
+    } while (0)
+#define SIG_CHECK_LAUNCH(name)                                                      \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            sig_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+            return 2;                                                               \
+        }                                                                           \
+    } while (0)
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// plain cast keeps NaN a NaN and lowers to v_cvt_pk_bf16_f32 (MI355X_MICROARCH correctness table)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- wave reductions (64 lanes) ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- LDS-DMA: 16 B per lane, LDS destination = wave-uniform base + lane*16 ---------------------
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// transposed LDS read: per 16-lane group a 4x16 block of 16-bit elements, delivered column-major
+__device__ __forceinline__ bf16x4_t lds_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)p);
+}
+
+// XCD-aware bijective block remap: blocks b and b+8 share an XCD (speed only, never correctness)
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+static inline int sig_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,64 @@
+// Internal launcher interface between the kernel translation units and capi.hip.
+#pragma once
+#include "sig_common.h"
+
+// ---- GEMM ---------------------------------------------------------------------------------------
+enum SigEpilogue {
+    SIG_EPI_F32 = 0,            // out f32 = acc
+    SIG_EPI_BF16 = 1,           // out bf16 = acc
+    SIG_EPI_BIAS_F32 = 2,       // out f32 = acc + bias
+    SIG_EPI_BIAS_BF16 = 3,      // out bf16 = acc + bias
+    SIG_EPI_BIAS_RES_F32 = 4,   // out f32 = acc + bias + res   (res may alias out)
+    SIG_EPI_BIAS_GELU_BF16 = 5, // aux bf16 = acc + bias (if aux), out bf16 = QuickGELU(acc + bias)
+    SIG_EPI_DGELU_BF16 = 6,     // out bf16 = acc * QuickGELU'(aux)
+};
+
+struct SigGemmNT {
+    const bf16_t* A;   // [Mpad, lda]  rows >= M readable (buffers are padded to 128 rows)
+    const bf16_t* Bt;  // [N, ldb]
+    int lda, ldb;
+    int M, N, K;
+    void* out;         // f32 or bf16 [M, ldo]
+    int ldo;
+    const float* bias; // [N]
+    const float* res;  // [M, ldr] f32
+    int ldr;
+    void* aux;         // bf16 [M, ldaux]
+    int ldaux;
+};
+int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st);
+
+struct SigGemmTN {
+    const bf16_t* P;  // [Mr, ldp], columns I
+    const bf16_t* Q;  // [Mr, ldq], columns J
+    int ldp, ldq;
+    int Mr, I, J;     // Mr multiple of 64; pad rows must be zero in P or Q
+    float* out;       // [I, ldo] f32, accumulated with atomics
+    int ldo;
+    int split;        // 0 = choose
+    int m_chunk;      // filled by the launcher
+};
+int sig_launch_gemm_tn(const SigGemmTN& p, hipStream_t st);
+
+// ---- row-wise kernels (rowops.hip) ----------------------------------------------------------------
+int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y_bf16, float* y_f32,
+                             float* mean, float* rstd, int M, int D, float eps, hipStream_t st);
+int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
+                             const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma,
+                             float* dbeta, int M, int D, hipStream_t st);
+int sig_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
+int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st);
+int sig_launch_colsum_bf16(const bf16_t* a, int lda, int M, int N, float* out, hipStream_t st);
+int sig_launch_colsum_f32(const float* a, int lda, int M, int N, float* out, hipStream_t st);
+int sig_launch_im2col(const float* img, bf16_t* out, int nimg, int H, int W, int P, hipStream_t st);
+int sig_launch_embed_assemble(const float* tok, const float* cls_emb, const float* pos, const float* cv_embed,
+                              const int64_t* cam, float sie_coe, const float* g, const float* b, float* x,
+                              float* pre_ln, float* mean, float* rstd, int S, int B, int L, int D, float eps,
+                              hipStream_t st);
+int sig_launch_embed_bwd(const float* dx_pre, float* dtok_f32, bf16_t* dtok_bf16, float* dcls, float* dpos,
+                         float* dcv, const int64_t* cam, float sie_coe, int S, int B, int L, int D, hipStream_t st);
+
+// ---- attention (attention.hip) ---------------------------------------------------------------------
+int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, hipStream_t st);
+int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
+                        int S, int L, int H, hipStream_t st);

@@ -1,0 +1,235 @@
+"""Per-kernel parity on a real MI355X: each HIP primitive, called through the C ABI, against a plain
+PyTorch fp32 evaluation of the same op on the same (bf16-rounded) inputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from signal_amd import ops
+    return ops
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float(((a - b).norm() / b.norm().clamp_min(1e-30)).detach())
+
+
+def padded(t, ops):
+    out = torch.zeros(ops.pad_rows(t.shape[0]), t.shape[1], dtype=t.dtype, device=t.device)
+    out[: t.shape[0]] = t
+    return out
+
+
+GEMM_SHAPES = [(774, 384, 128), (1000, 768, 3072), (4128, 2304, 768), (129, 128, 64)]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
+def test_gemm_nt_epilogues(dev, m, n, k):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    a = bf(torch.randn(m, k, generator=g)).to(dev)
+    # asymmetric operands (cdna guide: a symmetric B hides a transposed C write)
+    w = bf(torch.randn(n, k, generator=g) * 0.05 + torch.linspace(-0.02, 0.03, n)[:, None]).to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    res = torch.randn(m, n, generator=g).to(dev)
+    ap = padded(a, ops)
+    ref = a.float() @ w.float().t()
+
+    out = torch.zeros(ops.pad_rows(m), n, device=dev)
+    ops.gemm_nt(ap, w, m, ops.F32, out)
+    assert rel_err(out[:m], ref) < 2e-6
+    assert not bool(out[m:].abs().any()), "pad rows must stay untouched"
+
+    ops.gemm_nt(ap, w, m, ops.BIAS_F32, out, bias=bias)
+    assert rel_err(out[:m], ref + bias) < 2e-6
+
+    out.zero_()
+    ops.gemm_nt(ap, w, m, ops.BIAS_RES_F32, out, bias=bias, res=res)
+    assert rel_err(out[:m], ref + bias + res) < 2e-6
+    # in place on the residual stream
+    x = padded(res.clone(), ops)
+    ops.gemm_nt(ap, w, m, ops.BIAS_RES_F32, x, bias=bias, res=x)
+    assert rel_err(x[:m], ref + bias + res) < 2e-6
+
+    ob = torch.zeros(ops.pad_rows(m), n, device=dev, dtype=torch.bfloat16)
+    ops.gemm_nt(ap, w, m, ops.BF16, ob)
+    assert rel_err(ob[:m].float(), ref) < 3e-3
+    ops.gemm_nt(ap, w, m, ops.BIAS_BF16, ob, bias=bias)
+    assert rel_err(ob[:m].float(), ref + bias) < 3e-3
+
+    u = torch.zeros_like(ob)
+    ops.gemm_nt(ap, w, m, ops.BIAS_GELU_BF16, ob, bias=bias, aux=u)
+    pre = ref + bias
+    assert rel_err(u[:m].float(), pre) < 3e-3
+    assert rel_err(ob[:m].float(), pre * torch.sigmoid(1.702 * pre)) < 4e-3
+
+    # dgelu: out = acc * QuickGELU'(u)
+    uu = bf(torch.randn(m, n, generator=g)).to(dev)
+    ops.gemm_nt(ap, w, m, ops.DGELU_BF16, ob, aux=padded(uu, ops))
+    s = torch.sigmoid(1.702 * uu.float())
+    assert rel_err(ob[:m].float(), ref * (s * (1 + 1.702 * uu.float() * (1 - s)))) < 4e-3
+
+
+@pytest.mark.parametrize("mr,i,j", [(128, 128, 128), (896, 384, 128), (4160, 768, 256), (24832, 256, 128)])
+def test_gemm_tn(dev, mr, i, j):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(mr + i)
+    p = bf(torch.randn(mr, i, generator=g) * 0.1 + torch.linspace(-0.1, 0.2, i)[None]).to(dev)
+    q = bf(torch.randn(mr, j, generator=g)).to(dev)
+    ref = p.float().t() @ q.float()
+    for split in (0, 1, 3):
+        out = torch.zeros(i, j, device=dev)
+        ops.gemm_tn(p, q, out, split=split)
+        assert rel_err(out, ref) < 5e-6, f"split={split}"
+    # accumulates
+    ops.gemm_tn(p, q, out)
+    assert rel_err(out, 2 * ref) < 5e-6
+
+
+@pytest.mark.parametrize("m,d", [(774, 768), (1000, 512), (37, 128), (5, 1024)])
+def test_layernorm(dev, m, d):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(m * d)
+    x = (torch.randn(m, d, generator=g) * 2 + 0.5).to(dev)
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
+    b = (0.1 * torch.randn(d, generator=g)).to(dev)
+    yb = torch.zeros(m, d, device=dev, dtype=torch.bfloat16)
+    yf = torch.zeros(m, d, device=dev)
+    mean, rstd = torch.zeros(m, device=dev), torch.zeros(m, device=dev)
+    ops.layernorm_fwd(x, w, b, m, y_bf16=yb, y_f32=yf, mean=mean, rstd=rstd)
+    ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-5)
+    assert rel_err(yf, ref) < 1e-6
+    assert rel_err(yb.float(), ref) < 3e-3
+    assert rel_err(mean, x.mean(1)) < 1e-5
+
+    # backward (f32 and bf16 dy), with residual gradient and parameter grads
+    dy = torch.randn(m, d, generator=g).to(dev)
+    dres = torch.randn(m, d, generator=g).to(dev)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5).backward(dy)
+    for dyt, tol in ((dy, 2e-6), (bf(dy), 4e-3)):
+        dxf = torch.zeros(m, d, device=dev)
+        dxb = torch.zeros(m, d, device=dev, dtype=torch.bfloat16)
+        dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+        ops.layernorm_bwd(dyt, x, w, mean, rstd, m, dres=dres, dx_f32=dxf, dx_bf16=dxb, dgamma=dg, dbeta=db)
+        assert rel_err(dxf, xr.grad + dres) < tol
+        assert rel_err(dxb.float(), xr.grad + dres) < 4e-3
+        assert rel_err(dg, wr.grad) < max(tol, 2e-5)
+        assert rel_err(db, br.grad) < max(tol, 2e-5)
+
+
+def _attn_ref(qkv, s, l, h):
+    d = h * 64
+    q, k, v = qkv.float().reshape(s, l, 3, h, 64).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+    return (att @ v).permute(0, 2, 1, 3).reshape(s * l, d), torch.logsumexp(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+
+
+@pytest.mark.parametrize("s,l,h", [(3, 129, 2), (6, 129, 12), (2, 17, 1), (2, 128, 2), (1, 144, 3)])
+def test_attention_fwd_bwd(dev, s, l, h):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(s * l + h)
+    d = h * 64
+    qkv = bf(torch.randn(s * l, 3 * d, generator=g) * 1.5).to(dev)
+    qkv_p = padded(qkv, ops)
+    out = torch.zeros(ops.pad_rows(s * l), d, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(s, h, l, device=dev)
+    ops.attn_fwd(qkv_p, out, lse, s, l, h)
+    qr = qkv.float().requires_grad_(True)
+    ref, ref_lse = _attn_ref(qr, s, l, h)
+    assert rel_err(out[: s * l].float(), ref) < 6e-3
+    assert rel_err(lse, ref_lse) < 1e-5
+    assert not bool(out[s * l:].float().abs().any()), "pad rows must stay untouched"
+
+    dout = bf(torch.randn(s * l, d, generator=g)).to(dev)
+    ref.backward(dout.float())
+    dqkv = torch.zeros_like(qkv_p)
+    ops.attn_bwd(qkv_p, out, padded(dout, ops), lse, dqkv, s, l, h)
+    gq, gk, gv = (qr.grad[:, i * d:(i + 1) * d] for i in range(3))
+    hq, hk, hv = (dqkv[: s * l, i * d:(i + 1) * d].float() for i in range(3))
+    assert rel_err(hv, gv) < 1e-2
+    assert rel_err(hk, gk) < 1.5e-2
+    assert rel_err(hq, gq) < 1.5e-2
+
+
+def test_cast_transpose_colsum(dev):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    w = torch.randn(3072, 768, generator=g).to(dev)
+    d1 = torch.empty(3072, 768, device=dev, dtype=torch.bfloat16)
+    d2 = torch.empty(768, 3072, device=dev, dtype=torch.bfloat16)
+    ops.cast_bf16(w, d1)
+    ops.transpose_cast_bf16(w, d2)
+    assert torch.equal(d1, bf(w))
+    assert torch.equal(d2, bf(w).t().contiguous())
+    odd = torch.randn(1003, generator=g).to(dev)
+    o = torch.empty(1003, device=dev, dtype=torch.bfloat16)
+    ops.cast_bf16(odd, o)
+    assert torch.equal(o, bf(odd))
+    for m, n in ((774, 768), (1000, 2304), (130, 512)):
+        a = torch.randn(ops.pad_rows(m), n, generator=g).to(dev)
+        for t in (a, bf(a)):
+            out = torch.zeros(n, device=dev)
+            ops.colsum(t, m, out)
+            assert rel_err(out, t[:m].float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("hw", [(256, 128), (128, 256)])
+def test_embed_front_end(dev, hw):
+    """im2col + conv1-as-GEMM + token assembly + ln_pre against the oracle's vit_embed."""
+    ops = _ops()
+    from oracle import signal_ref as O
+    cfg = O.RefConfig(size_train=hw, layers=1, use_a=False, use_b=False)
+    sd = O.init_state_dict(cfg, seed=5)
+    B = 2
+    img, _, cam = O.synthetic_batch(cfg, B, seed=6)
+    base = "clip_vision_encoder.base."
+    D, L, Lp = cfg.width, cfg.tokens, cfg.tokens - 1
+    S = 3 * B
+    imgs = torch.cat([img[m] for m in O.MODALITIES]).to(dev)
+    patches = torch.zeros(ops.pad_rows(S * Lp), 3 * 256, device=dev, dtype=torch.bfloat16)
+    ops.im2col(imgs, patches, 16)
+    wconv = bf(sd[base + "conv1.weight"].reshape(D, -1)).to(dev)
+    tok = torch.zeros(ops.pad_rows(S * Lp), D, device=dev)
+    ops.gemm_nt(patches, wconv, S * Lp, ops.F32, tok)
+    x = torch.zeros(S * L, D, device=dev)
+    pre = torch.zeros(S * L, D, device=dev)
+    mean, rstd = torch.zeros(S * L, device=dev), torch.zeros(S * L, device=dev)
+    cv = sd["clip_vision_encoder.cv_embed"].reshape(-1, D).to(dev)
+    ops.embed_assemble(tok, sd[base + "class_embedding"].to(dev), sd[base + "positional_embedding"].to(dev), cv,
+                       cam.to(dev), cfg.sie_coe, sd[base + "ln_pre.weight"].to(dev), sd[base + "ln_pre.bias"].to(dev),
+                       x, pre, mean, rstd, S, B, L, D)
+    ref = torch.cat([O.vit_embed(sd, cfg, img[m], cfg.sie_coe * sd["clip_vision_encoder.cv_embed"][cam])
+                     for m in O.MODALITIES]).reshape(S * L, D)
+    assert rel_err(x.cpu(), ref) < 5e-3          # bf16 conv operands
+    # CLS rows involve no bf16 at all
+    assert rel_err(x.reshape(S, L, D)[:, 0].cpu(), ref.reshape(S, L, D)[:, 0]) < 1e-6
+
+    # backward of the assembly
+    dpre = torch.randn(S * L, D, device=dev)
+    dtok = torch.zeros(S * Lp, D, device=dev)
+    dtokb = torch.zeros(S * Lp, D, device=dev, dtype=torch.bfloat16)
+    dcls, dpos, dcv = torch.zeros(D, device=dev), torch.zeros(L, D, device=dev), torch.zeros_like(cv)
+    ops.embed_bwd(dpre, dtok, dtokb, dcls, dpos, dcv, cam.to(dev), cfg.sie_coe, S, B, L, D)
+    d3 = dpre.reshape(S, L, D)
+    assert rel_err(dtok, d3[:, 1:].reshape(-1, D)) < 1e-7
+    assert rel_err(dpos, d3.sum(0)) < 1e-5
+    assert rel_err(dcls, d3[:, 0].sum(0)) < 1e-5
+    ref_cv = torch.zeros_like(cv).index_add_(0, cam.to(dev).repeat(3), d3[:, 0] * cfg.sie_coe)
+    assert rel_err(dcv, ref_cv) < 1e-5
