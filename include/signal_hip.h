@@ -34,7 +34,10 @@ enum {
     SIG_GEMM_BIAS_BF16 = 3,     /* out bf16 = acc + bias                            */
     SIG_GEMM_BIAS_RES_F32 = 4,  /* out f32  = acc + bias + res  (res may alias out) */
     SIG_GEMM_BIAS_GELU_BF16 = 5,/* aux bf16 = acc + bias (if aux), out bf16 = QuickGELU(acc + bias) */
-    SIG_GEMM_DGELU_BF16 = 6     /* out bf16 = acc * QuickGELU'(aux)                 */
+    SIG_GEMM_DGELU_BF16 = 6,    /* out bf16 = acc * QuickGELU'(aux)                 */
+    SIG_GEMM_BIAS_GELUERF_BF16 = 7, /* as 5 with the exact-erf GELU (nn.GELU(), useA.py:356, DAS.py:59) */
+    SIG_GEMM_DGELUERF_BF16 = 8, /* out bf16 = acc * GELU_erf'(aux)                  */
+    SIG_GEMM_RES_F32 = 9        /* out f32  = acc + res                             */
 };
 
 /* out[M,N] = A[M,K] * Bt[N,K]^T (+ epilogue).  Every dense layer of the path: nn.Linear / MHA in-proj /
@@ -81,9 +84,146 @@ int sig_embed_assemble(const float* tok, const float* class_embedding, const flo
                        const float* cv_embed, const int64_t* cam_label, float sie_coe, const float* ln_w,
                        const float* ln_b, float* x, float* pre_ln, float* mean, float* rstd, int S, int B, int L,
                        int D, float eps, void* stream);
-int sig_embed_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dtok_bf16, float* d_class_embedding,
+int sig_embed_assemble_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dtok_bf16, float* d_class_embedding,
                   float* d_positional_embedding, float* d_cv_embed, const int64_t* cam_label, float sie_coe,
                   int S, int B, int L, int D, void* stream);
+
+/* ================================================================================================
+ * Stage-level entry points: one call per stage of VisionTransformer.forward (modeling/clip/model.py:447-488)
+ * and of its backward.  Token tensors are [M = S*L rows padded, columns]; S = 3*B sequences ordered
+ * modality-major (s = modality*B + b), so the reference's three backbone calls (make_model.py:181-183) are
+ * one batched problem.  "acts" structs are written by *_fwd and read by *_bwd; "grads" are f32 and
+ * ACCUMULATED (the caller zeroes them once per step).
+ * ================================================================================================ */
+typedef struct SigVitDims {
+    int S, B, L, D, H, F, out_dim;   /* sequences, per-modality batch, tokens, width, heads, MLP width, proj columns */
+} SigVitDims;
+
+/* --- patch embedding + CLS/camera/positional + ln_pre (clip/model.py:448-459, meta_arch.py:101-103) --- */
+typedef struct SigEmbedParams {
+    const uint16_t* w_conv;            /* bf16 [D, 3*P*P] = conv1.weight flattened */
+    const float *class_embedding, *positional_embedding, *cv_embed /* [cams, D] or NULL */, *ln_w, *ln_b;
+    float sie_coe;
+} SigEmbedParams;
+typedef struct SigEmbedActs {
+    uint16_t* patches;                 /* bf16 [S*(L-1) padded, 3*P*P] */
+    float* tok;                        /* f32  [S*(L-1) padded, D]     */
+    float* pre_ln;                     /* f32  [M, D] (NULL when no backward is needed) */
+    float *mean, *rstd;                /* [M] (may be NULL with pre_ln) */
+    float* x0;                         /* f32  [M padded, D]: the residual stream entering block 0 */
+} SigEmbedActs;
+typedef struct SigEmbedGrads {
+    float *w_conv, *class_embedding, *positional_embedding, *cv_embed, *ln_w, *ln_b;
+} SigEmbedGrads;
+int sig_embed_fwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedActs* a, const float* img,
+                  const int64_t* cam_label, int img_h, int img_w, int patch, void* stream);
+/* dx0: f32 [M,D] gradient of x0; scratch_dpre f32 [M,D]; scratch_dtok bf16 [S*(L-1) padded, D] (pad rows zero) */
+int sig_embed_bwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedActs* a, const SigEmbedGrads* g,
+                  const float* dx0, float* scratch_dpre, uint16_t* scratch_dtok, const int64_t* cam_label,
+                  int patch, void* stream);
+
+/* --- one ResidualAttentionBlock.forward_ori (clip/model.py:227-231) --- */
+typedef struct SigBlockParams {
+    const uint16_t *w_in, *w_out, *w_fc, *w_proj;      /* bf16 [3D,D] [D,D] [F,D] [D,F] (PyTorch [out,in] layout) */
+    const uint16_t *wt_in, *wt_out, *wt_fc, *wt_proj;  /* their transposes, backward only (may be NULL in fwd)    */
+    const float *b_in, *b_out, *b_fc, *b_proj, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+} SigBlockParams;
+typedef struct SigBlockActs {
+    float* x_in;                       /* f32 [Mp,D] block input (read) */
+    uint16_t* h1;  float *mean1, *rstd1;
+    uint16_t* qkv; float* lse;         /* bf16 [Mp,3D], f32 [S,H,L] */
+    uint16_t* attn;                    /* bf16 [Mp,D] */
+    float* x_mid;                      /* f32 [Mp,D] */
+    uint16_t* h2;  float *mean2, *rstd2;
+    uint16_t* u;                       /* bf16 [Mp,F] pre-activation (NULL when no backward is needed) */
+    uint16_t* g;                       /* bf16 [Mp,F] QuickGELU(u) */
+    float* x_out;                      /* f32 [Mp,D] block output (written) */
+} SigBlockActs;
+typedef struct SigBlockGrads {
+    float *w_in, *w_out, *w_fc, *w_proj, *b_in, *b_out, *b_fc, *b_proj, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+} SigBlockGrads;
+typedef struct SigBlockScratch {       /* reusable across blocks; pad rows must be zero */
+    uint16_t* du;                      /* bf16 [Mp,F]  */
+    uint16_t* dh;                      /* bf16 [Mp,D]  */
+    uint16_t* dqkv;                    /* bf16 [Mp,3D] */
+    float* dx_mid;                     /* f32  [Mp,D]  */
+    uint16_t* dx_mid_b;                /* bf16 [Mp,D]  */
+} SigBlockScratch;
+int sig_block_fwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockActs* a, void* stream);
+/* dx_out (f32) and dx_out_b (its bf16 copy) are the gradient of x_out; writes dx_in and dx_in_b. */
+int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockActs* a, const SigBlockGrads* g,
+                  const SigBlockScratch* s, const float* dx_out, const uint16_t* dx_out_b, float* dx_in,
+                  uint16_t* dx_in_b, void* stream);
+
+/* --- ln_post + x @ proj on all tokens (clip/model.py:485-488) --- */
+typedef struct SigHeadParams {
+    const uint16_t* proj_t;            /* bf16 [out_dim, D] = proj^T (forward operand)  */
+    const uint16_t* proj;              /* bf16 [D, out_dim]          (dgrad operand)    */
+    const float *ln_w, *ln_b;
+} SigHeadParams;
+typedef struct SigHeadActs {
+    float* x;                          /* f32 [Mp,D] last block output (read) */
+    uint16_t* hp; float *mean, *rstd;  /* bf16 [Mp,D] ln_post output */
+    float* tokens;                     /* f32 [Mp,out_dim] */
+} SigHeadActs;
+typedef struct SigHeadGrads { float *proj, *ln_w, *ln_b; } SigHeadGrads;
+int sig_head_fwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs* a, void* stream);
+/* dtokens f32 [Mp,out_dim] (pad rows zero); scratch_dtok_b bf16 [Mp,out_dim]; scratch_dh bf16 [Mp,D] */
+int sig_head_bwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs* a, const SigHeadGrads* g,
+                 const float* dtokens, uint16_t* scratch_dtok_b, uint16_t* scratch_dh, float* dx, uint16_t* dx_b,
+                 void* stream);
+
+/* ================================================================================================
+ * SIM -- Select_Interactive_Module (modeling/AddModule/useA.py:426-476), on the projected tokens
+ * tokens f32 [S*L padded, 512] (row s*L = CLS of sequence s = modality*B + b, rows s*L+1.. = patches).
+ * ================================================================================================ */
+typedef struct SigSimParams {
+    /* TokenSelection.W_q / W_k (f32 [512,512] + bias); W_v is dead in the reference (useA.py:46-48) */
+    const float *sel_wq, *sel_bq, *sel_wk, *sel_bk;
+    /* ModalInteractive: cross_attn.in_proj (rows 0..511 = q, 512..1535 = k|v), out_proj, ffn.0, ffn.2, norm1/2 */
+    const uint16_t *w_q, *w_kv, *w_o, *w_f1, *w_f2;          /* bf16 [512,512] [1024,512] [512,512] [1024,512] [512,1024] */
+    const uint16_t *wt_q, *wt_kv, *wt_o, *wt_f1, *wt_f2;     /* transposes, backward only */
+    const float *b_q, *b_kv, *b_o, *b_f1, *b_f2, *n1_w, *n1_b, *n2_w, *n2_b;
+    int topk;                                                /* MODEL.TOPK: k1 = topk, k2 = 2*topk */
+} SigSimParams;
+typedef struct SigSimActs {
+    float *qprime, *cconst, *intra, *inter;  /* [B,3,512] [B,3] [B,3,Lp] [B,3,3Lp] : selection scores (raw, pre-softmax) */
+    float* mask_f;                           /* [3,B,Lp] 0/1 : TokenSelection.last_masks */
+    uint8_t* mask_u8;                        /* [3,B,Lp] or NULL */
+    uint16_t* sel;                           /* bf16 [B*3*Lp padded, 512] masked tokens, rows (b, modality, j) */
+    uint16_t* cls_b; float* cls_f;           /* [B*3 padded, 512] stacked CLS queries, rows (b, modality) */
+    float* qh;                               /* f32  [B*3 padded, 512] projected queries */
+    uint16_t* kv;                            /* bf16 [B*3*Lp padded, 1024] */
+    float* probs;                            /* f32  [B,24,3Lp] */
+    uint16_t* ao;                            /* bf16 [B*3 padded, 512] attention output */
+    float* y;  float* z1; uint16_t* z1_b; float *mean1, *rstd1;
+    uint16_t *f1_pre, *f1;                   /* bf16 [B*3 padded, 1024] */
+    float* y2; float *mean2, *rstd2;
+    float* out;                              /* f32 [B*3 padded, 512] == vars_total [B,1536] */
+} SigSimActs;
+typedef struct SigSimGrads {
+    float *w_q, *w_kv, *w_o, *w_f1, *w_f2, *b_q, *b_kv, *b_o, *b_f1, *b_f2, *n1_w, *n1_b, *n2_w, *n2_b;
+} SigSimGrads;
+typedef struct SigSimScratch {               /* pad rows zero */
+    float* dy2;  uint16_t* dy2_b;            /* [B*3 padded, 512]  */
+    uint16_t* df1;                           /* [B*3 padded, 1024] */
+    float* dz1;  float* dy; uint16_t* dy_b;  /* [B*3 padded, 512]  */
+    float* dao;  float* dqh; uint16_t* dqh_b;/* [B*3 padded, 512]  */
+    uint16_t* dkv;                           /* [B*3*Lp padded, 1024] */
+    uint16_t* dsel;                          /* [B*3*Lp padded, 512]  */
+    float* dcls;                             /* [B*3 padded, 512]  */
+} SigSimScratch;
+/* selection only (useA.py:223-251): masks from tokens */
+int sig_sim_select(const float* tokens, int B, int L, const SigSimParams* p, const SigSimActs* a, void* stream);
+/* selection + interaction (the whole Select_Interactive_Module.forward) */
+int sig_sim_fwd(const float* tokens, int B, int L, const SigSimParams* p, const SigSimActs* a, void* stream);
+/* dout f32 [B*3 padded,512]; dtokens f32 [S*L padded,512] is ACCUMULATED into */
+int sig_sim_bwd(const float* dout, int B, int L, const SigSimParams* p, const SigSimActs* a, const SigSimGrads* g,
+                const SigSimScratch* s, float* dtokens, void* stream);
+/* attention core of the interaction block, exposed for tests */
+int sig_xattn_fwd(const float* q, const uint16_t* kv, int B, int NK, uint16_t* out, float* probs, void* stream);
+int sig_xattn_bwd(const float* q, const uint16_t* kv, const float* probs, const float* dout, int B, int NK, float* dq,
+                  uint16_t* dkv, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,79 @@ SIGNATURES = {
     "sig_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp],
 }
 
+
+
+# ---- struct mirrors of include/signal_hip.h -----------------------------------------------------------
+def _struct(name, ptr_fields, tail=()):
+    fields = [(f, _vp) for f in ptr_fields] + list(tail)
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+class SigVitDims(C.Structure):
+    _fields_ = [(n, _i) for n in ("S", "B", "L", "D", "H", "F", "out_dim")]
+
+
+SigEmbedParams = _struct("SigEmbedParams", ["w_conv", "class_embedding", "positional_embedding", "cv_embed", "ln_w", "ln_b"],
+                         [("sie_coe", _f)])
+SigEmbedActs = _struct("SigEmbedActs", ["patches", "tok", "pre_ln", "mean", "rstd", "x0"])
+SigEmbedGrads = _struct("SigEmbedGrads", ["w_conv", "class_embedding", "positional_embedding", "cv_embed", "ln_w", "ln_b"])
+SigBlockParams = _struct("SigBlockParams", ["w_in", "w_out", "w_fc", "w_proj", "wt_in", "wt_out", "wt_fc", "wt_proj",
+                                             "b_in", "b_out", "b_fc", "b_proj", "ln1_w", "ln1_b", "ln2_w", "ln2_b"])
+SigBlockActs = _struct("SigBlockActs", ["x_in", "h1", "mean1", "rstd1", "qkv", "lse", "attn", "x_mid", "h2", "mean2", "rstd2",
+                                         "u", "g", "x_out"])
+SigBlockGrads = _struct("SigBlockGrads", ["w_in", "w_out", "w_fc", "w_proj", "b_in", "b_out", "b_fc", "b_proj",
+                                           "ln1_w", "ln1_b", "ln2_w", "ln2_b"])
+SigBlockScratch = _struct("SigBlockScratch", ["du", "dh", "dqkv", "dx_mid", "dx_mid_b"])
+SigHeadParams = _struct("SigHeadParams", ["proj_t", "proj", "ln_w", "ln_b"])
+SigHeadActs = _struct("SigHeadActs", ["x", "hp", "mean", "rstd", "tokens"])
+SigHeadGrads = _struct("SigHeadGrads", ["proj", "ln_w", "ln_b"])
+SigSimParams = _struct("SigSimParams", ["sel_wq", "sel_bq", "sel_wk", "sel_bk", "w_q", "w_kv", "w_o", "w_f1", "w_f2",
+                                         "wt_q", "wt_kv", "wt_o", "wt_f1", "wt_f2", "b_q", "b_kv", "b_o", "b_f1", "b_f2",
+                                         "n1_w", "n1_b", "n2_w", "n2_b"], [("topk", _i)])
+SigSimActs = _struct("SigSimActs", ["qprime", "cconst", "intra", "inter", "mask_f", "mask_u8", "sel", "cls_b", "cls_f", "qh",
+                                     "kv", "probs", "ao", "y", "z1", "z1_b", "mean1", "rstd1", "f1_pre", "f1", "y2", "mean2",
+                                     "rstd2", "out"])
+SigSimGrads = _struct("SigSimGrads", ["w_q", "w_kv", "w_o", "w_f1", "w_f2", "b_q", "b_kv", "b_o", "b_f1", "b_f2",
+                                       "n1_w", "n1_b", "n2_w", "n2_b"])
+SigSimScratch = _struct("SigSimScratch", ["dy2", "dy2_b", "df1", "dz1", "dy", "dy_b", "dao", "dqh", "dqh_b", "dkv", "dsel", "dcls"])
+
+SIGNATURES.update({
+    "sig_embed_assemble_bwd": SIGNATURES.pop("sig_embed_bwd"),
+    "sig_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sig_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "sig_block_fwd": [_vp, _vp, _vp, _vp],
+    "sig_block_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sig_head_fwd": [_vp, _vp, _vp, _vp],
+    "sig_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sig_sim_select": [_vp, _i, _i, _vp, _vp, _vp],
+    "sig_sim_fwd": [_vp, _i, _i, _vp, _vp, _vp],
+    "sig_sim_bwd": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sig_xattn_fwd": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "sig_xattn_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+})
+
+
+def ref(struct):
+    """pointer argument for a struct"""
+    return C.cast(C.pointer(struct), _vp)
+
+
+def fill(struct_cls, **tensors):
+    """Build a struct from name -> tensor / None / number; unknown names are an error."""
+    s = struct_cls()
+    names = {f[0] for f in struct_cls._fields_}
+    for k, v in tensors.items():
+        if k not in names:
+            raise KeyError(f"{struct_cls.__name__} has no field {k}")
+        if v is None:
+            setattr(s, k, None)
+        elif hasattr(v, "data_ptr"):
+            setattr(s, k, v.data_ptr())
+        else:
+            setattr(s, k, v)
+    return s
+
+
 _lib = None
 
 

@@ -21,6 +21,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-at
          "-fno-finite-math-only", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
 
 
+# translation units whose float results decide INTEGER outputs (top-k masks) are built without fast-math
+PRECISE = {"sim.hip"}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -49,7 +53,8 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            flags = [f for f in FLAGS if not (src in PRECISE and f in ("-ffast-math", "-fno-finite-math-only"))]
+            jobs.append([hipcc, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -16,7 +16,9 @@ void sig_set_error(const char* fmt, ...) {
 
 static_assert(SIG_GEMM_F32 == SIG_EPI_F32 && SIG_GEMM_BF16 == SIG_EPI_BF16 && SIG_GEMM_BIAS_F32 == SIG_EPI_BIAS_F32 &&
                   SIG_GEMM_BIAS_BF16 == SIG_EPI_BIAS_BF16 && SIG_GEMM_BIAS_RES_F32 == SIG_EPI_BIAS_RES_F32 &&
-                  SIG_GEMM_BIAS_GELU_BF16 == SIG_EPI_BIAS_GELU_BF16 && SIG_GEMM_DGELU_BF16 == SIG_EPI_DGELU_BF16,
+                  SIG_GEMM_BIAS_GELU_BF16 == SIG_EPI_BIAS_GELU_BF16 && SIG_GEMM_DGELU_BF16 == SIG_EPI_DGELU_BF16 &&
+                  SIG_GEMM_BIAS_GELUERF_BF16 == SIG_EPI_BIAS_GELUERF_BF16 && SIG_GEMM_DGELUERF_BF16 == SIG_EPI_DGELUERF_BF16 &&
+                  SIG_GEMM_RES_F32 == SIG_EPI_RES_F32,
               "public and internal epilogue ids must agree");
 
 extern "C" {
@@ -84,7 +86,7 @@ int sig_embed_assemble(const float* tok, const float* class_embedding, const flo
     return sig_launch_embed_assemble(tok, class_embedding, positional_embedding, cv_embed, cam_label, sie_coe, ln_w, ln_b,
                                      x, pre_ln, mean, rstd, S, B, L, D, eps, (hipStream_t)stream);
 }
-int sig_embed_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dtok_bf16, float* d_class_embedding,
+int sig_embed_assemble_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dtok_bf16, float* d_class_embedding,
                   float* d_positional_embedding, float* d_cv_embed, const int64_t* cam_label, float sie_coe, int S, int B,
                   int L, int D, void* stream) {
     return sig_launch_embed_bwd(d_pre_ln, dtok_f32, dtok_bf16, d_class_embedding, d_positional_embedding, d_cv_embed,

@@ -24,6 +24,11 @@ __device__ __forceinline__ float quick_gelu_grad_f(float u) {
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 
+__device__ __forceinline__ float gelu_erf_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float u) {
+    return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,30 +107,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
             const int n = n0 + wn + j * 16 + g * 4;
             f32x4_t v = acc[i][j];
             if (EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 ||
-                EPI == SIG_EPI_BIAS_GELU_BF16) {
+                EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) {
                 const f32x4_t b = *(const f32x4_t*)(p.bias + n);
                 v += b;
             }
-            if (EPI == SIG_EPI_BIAS_RES_F32) {
+            if (EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
                 const f32x4_t r = *(const f32x4_t*)(p.res + (size_t)m * p.ldr + n);
                 v += r;
             }
-            if (EPI == SIG_EPI_BIAS_GELU_BF16) {
+            if (EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) {
                 if (p.aux) {  // pre-activation kept for backward
                     uint2 u2 = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     *(uint2*)((bf16_t*)p.aux + (size_t)m * p.ldaux + n) = u2;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = EPI == SIG_EPI_BIAS_GELU_BF16 ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
             }
-            if (EPI == SIG_EPI_DGELU_BF16) {
+            if (EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_DGELUERF_BF16) {
                 const uint2 u2 = *(const uint2*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
-                v[0] *= quick_gelu_grad_f(bf2f((bf16_t)(u2.x & 0xffff)));
-                v[1] *= quick_gelu_grad_f(bf2f((bf16_t)(u2.x >> 16)));
-                v[2] *= quick_gelu_grad_f(bf2f((bf16_t)(u2.y & 0xffff)));
-                v[3] *= quick_gelu_grad_f(bf2f((bf16_t)(u2.y >> 16)));
+                const float uu[4] = {bf2f((bf16_t)(u2.x & 0xffff)), bf2f((bf16_t)(u2.x >> 16)), bf2f((bf16_t)(u2.y & 0xffff)),
+                                     bf2f((bf16_t)(u2.y >> 16))};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(uu[e]) : gelu_erf_grad_f(uu[e]);
             }
-            if (EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32) {
+            if (EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
                 *(f32x4_t*)((float*)p.out + (size_t)m * p.ldo + n) = v;
             } else {
                 uint2 o2 = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -166,6 +171,13 @@ int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st) {
         case SIG_EPI_DGELU_BF16:
             SIG_CHECK_ARG(p.aux && (p.ldaux & 3) == 0, "gemm_nt: pre-activation missing");
             return launch_nt<SIG_EPI_DGELU_BF16>(p, st);
+        case SIG_EPI_BIAS_GELUERF_BF16: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_GELUERF_BF16>(p, st);
+        case SIG_EPI_DGELUERF_BF16:
+            SIG_CHECK_ARG(p.aux && (p.ldaux & 3) == 0, "gemm_nt: pre-activation missing");
+            return launch_nt<SIG_EPI_DGELUERF_BF16>(p, st);
+        case SIG_EPI_RES_F32:
+            SIG_CHECK_ARG(p.res && (p.ldr & 3) == 0, "gemm_nt: residual missing");
+            return launch_nt<SIG_EPI_RES_F32>(p, st);
     }
     sig_set_error("gemm_nt: unknown epilogue %d", epi);
     return 1;

@@ -11,6 +11,9 @@ enum SigEpilogue {
     SIG_EPI_BIAS_RES_F32 = 4,   // out f32 = acc + bias + res   (res may alias out)
     SIG_EPI_BIAS_GELU_BF16 = 5, // aux bf16 = acc + bias (if aux), out bf16 = QuickGELU(acc + bias)
     SIG_EPI_DGELU_BF16 = 6,     // out bf16 = acc * QuickGELU'(aux)
+    SIG_EPI_BIAS_GELUERF_BF16 = 7, // aux bf16 = acc + bias (if aux), out bf16 = GELU_erf(acc + bias)
+    SIG_EPI_DGELUERF_BF16 = 8,  // out bf16 = acc * GELU_erf'(aux)
+    SIG_EPI_RES_F32 = 9,        // out f32 = acc + res
 };
 
 struct SigGemmNT {
@@ -60,5 +63,17 @@ int sig_launch_embed_bwd(const float* dx_pre, float* dtok_f32, bf16_t* dtok_bf16
 
 // ---- attention (attention.hip) ---------------------------------------------------------------------
 int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, hipStream_t st);
+// ---- SIM (sim.hip) ------------------------------------------------------------------------------------
+int sig_launch_sim_select(const float* tokens, int B, int L, const float* Wq, const float* bq, const float* Wk,
+                          const float* bk, int topk, float* qprime, float* cconst, float* intra, float* inter,
+                          float* mask_f, unsigned char* mask_u8, hipStream_t st);
+int sig_launch_sim_gather(const float* tokens, const float* mask_f, int B, int L, bf16_t* sel, bf16_t* cls_b, float* cls_f,
+                          hipStream_t st);
+int sig_launch_sim_gather_bwd(const bf16_t* dsel, const float* dcls, const float* mask_f, int B, int L, float* dtokens,
+                              hipStream_t st);
+int sig_launch_xattn_fwd(const float* q, const bf16_t* kv, int B, int NK, bf16_t* out, float* probs, hipStream_t st);
+int sig_launch_xattn_bwd(const float* q, const bf16_t* kv, const float* probs, const float* dout, int B, int NK, float* dq,
+                         bf16_t* dkv, hipStream_t st);
+
 int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
                         int S, int L, int H, hipStream_t st);

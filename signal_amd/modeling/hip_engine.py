@@ -1,0 +1,424 @@
+"""Host side of the HIP path: owns the flat parameter / packed-weight storage and the activation
+workspaces, and exposes the backbone (three modalities batched as one [3B,L,D] problem) and SIM as
+torch.autograd.Functions whose forward/backward are sequences of C-ABI calls on the current stream.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every FLOP of these stages runs
+in signal_amd/csrc.  There is no fallback: without a GPU or without the built library this raises."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import _lib
+from .._lib import fill, ref
+from ..ops import pad_rows
+
+BF = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class FlatParams:
+    """All parameters the HIP stages read live in ONE f32 buffer (views are re-pointed into it), their
+    gradients in one f32 buffer of the same layout, and the bf16 operands of the GEMMs in one bf16
+    buffer: packing is one cast kernel over the whole buffer plus one transpose per matrix."""
+
+    def __init__(self, named: Dict[str, torch.nn.Parameter], device):
+        self.names = list(named)
+        self.params = [named[n] for n in self.names]
+        self.offsets, off = {}, 0
+        for n, p in zip(self.names, self.params):
+            self.offsets[n] = off
+            off += (p.numel() + 63) // 64 * 64          # keep every tensor 256-B aligned
+        self.total = off
+        self.device = device
+        self.data = torch.zeros(off, dtype=F32, device=device)
+        self.grad = torch.zeros(off, dtype=F32, device=device)
+        self.bf16 = torch.zeros(off, dtype=BF, device=device)
+        with torch.no_grad():
+            for n, p in zip(self.names, self.params):
+                v = self.view(self.data, n, p.shape)
+                v.copy_(p.data)
+                p.data = v
+        self._versions = None
+        self._ptrs = [p.data_ptr() for p in self.params]
+        self.byname = dict(zip(self.names, self.params))
+
+    def view(self, flat, name, shape=None):
+        o = self.offsets[name]
+        shape = self.byname[name].shape if shape is None else shape
+        n = 1
+        for s in shape:
+            n *= s
+        return flat[o:o + n].view(shape)
+
+    def span(self, prefix):
+        """[lo, hi) element range of the (contiguous) group of parameters whose name starts with prefix."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefix)]
+        if not idx:
+            return None
+        if idx != list(range(idx[0], idx[-1] + 1)):
+            raise RuntimeError(f"parameters under {prefix} are not contiguous in the flat buffer")
+        last = self.names[idx[-1]]
+        hi = self.offsets[last] + (self.byname[last].numel() + 63) // 64 * 64
+        return self.offsets[self.names[idx[0]]], hi
+
+    def intact(self) -> bool:
+        return all(p.data_ptr() == q for p, q in zip(self.params, self._ptrs))
+
+    def stale(self) -> bool:
+        v = tuple(p._version for p in self.params)
+        if v != self._versions:
+            self._versions = v
+            return True
+        return False
+
+
+class _Ws:
+    """Zero-initialised, row-padded buffers (pad rows are never written, so they stay zero)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bytes = 0
+
+    def z(self, rows, cols, dtype=F32):
+        t = torch.zeros(pad_rows(rows), cols, dtype=dtype, device=self.device)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+    def v(self, n, dtype=F32):
+        t = torch.zeros(n, dtype=dtype, device=self.device)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+
+class HipPath:
+    def __init__(self, model):
+        self.model = model
+        self.flat: Optional[FlatParams] = None
+        self._vit_ws: Dict[tuple, list] = {}
+        self._sim_ws: Dict[tuple, list] = {}
+        enc = model.clip_vision_encoder
+        b = enc.base
+        self.D, self.H, self.layers, self.out_dim, self.patch = b.width, b.heads, b.layers, b.output_dim, b.patch
+        self.F = 4 * self.D
+        self.L = b.h_resolution * b.w_resolution + 1
+        self.img_hw = (b.h_resolution * b.patch, b.w_resolution * b.patch)
+
+    # ------------------------------------------------------------------ parameters
+    def _hip_named_params(self) -> Dict[str, torch.nn.Parameter]:
+        m = self.model
+        out = {}
+        for n, p in m.named_parameters():
+            if n.startswith(("clip_vision_encoder.", "SIM.", "AlignM.")):
+                out[n] = p
+        return out
+
+    def prepare(self, device):
+        """(Re)build flat storage if needed and refresh the bf16 operands when a parameter changed."""
+        if device.type != "cuda":
+            raise _lib.SignalHipError("signal_amd runs on an MI355X only: move the model and inputs to 'cuda' "
+                                      "(there is no CPU path; the CPU oracle lives in oracle/ and is test-only)")
+        _lib.load()
+        if self.flat is None or self.flat.device != device or not self.flat.intact():
+            named = self._hip_named_params()
+            if any(p.device != device for p in named.values()):
+                raise _lib.SignalHipError("model parameters are not on the input's device: call model.to(device) first")
+            self.flat = FlatParams(named, device)
+            self._build_structs()
+        if self.flat.stale():
+            self._pack()
+
+    def _pk(self, name):      # bf16 view of a parameter (same layout as f32)
+        return self.flat.view(self.flat.bf16, name)
+
+    def _g(self, name):       # f32 gradient view
+        return self.flat.view(self.flat.grad, name)
+
+    def _p(self, name):
+        return self.flat.byname[name].data
+
+    def grads_of(self, prefix, names):
+        """One copy of the group's gradient range, returned as per-parameter views (autograd adopts them)."""
+        lo, hi = self.flat.span(prefix)
+        chunk = self.flat.grad[lo:hi].clone()
+        out = []
+        for n in names:
+            o = self.flat.offsets[n] - lo
+            p = self.flat.byname[n]
+            out.append(chunk[o:o + p.numel()].view(p.shape))
+        return tuple(out)
+
+    def zero_grads_of(self, prefix):
+        lo, hi = self.flat.span(prefix)
+        self.flat.grad[lo:hi].zero_()
+
+    def _build_structs(self):
+        fl, dev = self.flat, self.flat.device
+        base = "clip_vision_encoder.base."
+        self._byname = fl.byname
+        self._transposed: Dict[str, torch.Tensor] = {}
+
+        def T(name, rows, cols):   # storage for the transposed bf16 copy of a [rows, cols] matrix
+            t = torch.zeros(cols, rows, dtype=BF, device=dev)
+            self._transposed[name] = t
+            return t
+
+        D, Fd, O = self.D, self.F, self.out_dim
+        m = self.model
+        cv = "clip_vision_encoder.cv_embed" if "clip_vision_encoder.cv_embed" in self._byname else None
+        self.embed_p = fill(_lib.SigEmbedParams, w_conv=self._pk(base + "conv1.weight"),
+                            class_embedding=self._p(base + "class_embedding"),
+                            positional_embedding=self._p(base + "positional_embedding"),
+                            cv_embed=self._p(cv) if cv else None, ln_w=self._p(base + "ln_pre.weight"),
+                            ln_b=self._p(base + "ln_pre.bias"), sie_coe=float(m.clip_vision_encoder.sie_xishu))
+        self.embed_g = fill(_lib.SigEmbedGrads, w_conv=self._g(base + "conv1.weight"),
+                            class_embedding=self._g(base + "class_embedding"),
+                            positional_embedding=self._g(base + "positional_embedding"),
+                            cv_embed=self._g(cv) if cv else None, ln_w=self._g(base + "ln_pre.weight"),
+                            ln_b=self._g(base + "ln_pre.bias"))
+        self.block_p, self.block_g = [], []
+        for i in range(self.layers):
+            p = f"{base}transformer.resblocks.{i}."
+            names = dict(w_in=p + "attn.in_proj_weight", w_out=p + "attn.out_proj.weight", w_fc=p + "mlp.c_fc.weight",
+                         w_proj=p + "mlp.c_proj.weight", b_in=p + "attn.in_proj_bias", b_out=p + "attn.out_proj.bias",
+                         b_fc=p + "mlp.c_fc.bias", b_proj=p + "mlp.c_proj.bias", ln1_w=p + "ln_1.weight",
+                         ln1_b=p + "ln_1.bias", ln2_w=p + "ln_2.weight", ln2_b=p + "ln_2.bias")
+            shapes = dict(w_in=(3 * D, D), w_out=(D, D), w_fc=(Fd, D), w_proj=(D, Fd))
+            kw = {}
+            for k, n in names.items():
+                kw[k] = self._pk(n) if k.startswith("w_") else self._p(n)
+            for k, (r, c) in shapes.items():
+                kw["wt_" + k[2:]] = T(names[k], r, c)
+            self.block_p.append(fill(_lib.SigBlockParams, **kw))
+            self.block_g.append(fill(_lib.SigBlockGrads, **{k: self._g(n) for k, n in names.items()}))
+        self.proj_t = T(base + "proj", D, O)      # forward operand proj^T [O, D]
+        self.head_p = fill(_lib.SigHeadParams, proj_t=self.proj_t, proj=self._pk(base + "proj"),
+                           ln_w=self._p(base + "ln_post.weight"), ln_b=self._p(base + "ln_post.bias"))
+        self.head_g = fill(_lib.SigHeadGrads, proj=self._g(base + "proj"), ln_w=self._g(base + "ln_post.weight"),
+                           ln_b=self._g(base + "ln_post.bias"))
+        self.vit_param_names = [n for n in fl.names if n.startswith("clip_vision_encoder.")]
+
+        self.sim_p = self.sim_g = None
+        if "SIM.token_selection.W_q.weight" in self._byname:
+            s, mi = "SIM.token_selection.", "SIM.modal_interactive."
+            d = 512
+            inw, inb = mi + "cross_attn.in_proj_weight", mi + "cross_attn.in_proj_bias"
+            w_in_bf, g_in = self._pk(inw), self._g(inw)
+            b_in, gb_in = self._p(inb), self._g(inb)
+            self._sim_T = dict(q=torch.zeros(d, d, dtype=BF, device=dev), kv=torch.zeros(d, 2 * d, dtype=BF, device=dev))
+            self.sim_p = fill(
+                _lib.SigSimParams, sel_wq=self._p(s + "W_q.weight"), sel_bq=self._p(s + "W_q.bias"),
+                sel_wk=self._p(s + "W_k.weight"), sel_bk=self._p(s + "W_k.bias"),
+                w_q=w_in_bf[:d], w_kv=w_in_bf[d:], w_o=self._pk(mi + "cross_attn.out_proj.weight"),
+                w_f1=self._pk(mi + "ffn.0.weight"), w_f2=self._pk(mi + "ffn.2.weight"),
+                wt_q=self._sim_T["q"], wt_kv=self._sim_T["kv"], wt_o=T(mi + "cross_attn.out_proj.weight", d, d),
+                wt_f1=T(mi + "ffn.0.weight", 2 * d, d), wt_f2=T(mi + "ffn.2.weight", d, 2 * d),
+                b_q=b_in[:d], b_kv=b_in[d:], b_o=self._p(mi + "cross_attn.out_proj.bias"),
+                b_f1=self._p(mi + "ffn.0.bias"), b_f2=self._p(mi + "ffn.2.bias"),
+                n1_w=self._p(mi + "norm1.weight"), n1_b=self._p(mi + "norm1.bias"),
+                n2_w=self._p(mi + "norm2.weight"), n2_b=self._p(mi + "norm2.bias"), topk=int(m.SIM.token_selection.k1))
+            self.sim_g = fill(
+                _lib.SigSimGrads, w_q=g_in[:d], w_kv=g_in[d:], w_o=self._g(mi + "cross_attn.out_proj.weight"),
+                w_f1=self._g(mi + "ffn.0.weight"), w_f2=self._g(mi + "ffn.2.weight"), b_q=gb_in[:d], b_kv=gb_in[d:],
+                b_o=self._g(mi + "cross_attn.out_proj.bias"), b_f1=self._g(mi + "ffn.0.bias"),
+                b_f2=self._g(mi + "ffn.2.bias"), n1_w=self._g(mi + "norm1.weight"), n1_b=self._g(mi + "norm1.bias"),
+                n2_w=self._g(mi + "norm2.weight"), n2_b=self._g(mi + "norm2.bias"))
+            self.sim_param_names = [n for n in fl.names if n.startswith(mi)]
+            self._sim_in_w = inw
+
+    def _pack(self):
+        """f32 -> bf16 for every parameter in one kernel, then the transposed copies."""
+        fl, st = self.flat, _stream()
+        _lib.call("sig_cast_bf16", fl.data.data_ptr(), fl.bf16.data_ptr(), fl.total, st)
+        for name, t in self._transposed.items():
+            src = self._byname[name].data
+            r, c = (src.shape[0], src.numel() // src.shape[0])
+            _lib.call("sig_transpose_cast_bf16", src.data_ptr(), t.data_ptr(), r, c, st)
+        if self.sim_p is not None:
+            w = self._byname[self._sim_in_w].data
+            _lib.call("sig_transpose_cast_bf16", w[:512].data_ptr(), self._sim_T["q"].data_ptr(), 512, 512, st)
+            _lib.call("sig_transpose_cast_bf16", w[512:].data_ptr(), self._sim_T["kv"].data_ptr(), 1024, 512, st)
+
+    # ------------------------------------------------------------------ backbone
+    def _alloc_vit(self, S, B, train):
+        dev, D, Fd, O, L, H = self.flat.device, self.D, self.F, self.out_dim, self.L, self.H
+        M, Mt, K = S * L, S * (L - 1), 3 * self.patch * self.patch
+        w = _Ws(dev)
+        ws = {"S": S, "B": B, "M": M, "train": train}
+        ws["dims"] = _lib.SigVitDims(S, B, L, D, H, Fd, O)
+        ws["img"] = torch.empty(S, 3, *self.img_hw, dtype=F32, device=dev)
+        ws["patches"], ws["tok"] = w.z(Mt, K, BF), w.z(Mt, D)
+        ws["pre_ln"] = w.z(M, D) if train else None
+        ws["emean"], ws["erstd"] = (w.v(M), w.v(M)) if train else (None, None)
+        nx = self.layers + 1 if train else 2
+        ws["x"] = [w.z(M, D) for _ in range(nx)]
+        nset = self.layers if train else 1
+        acts = []
+        for _ in range(nset):
+            acts.append(dict(h1=w.z(M, D, BF), mean1=w.v(M), rstd1=w.v(M), qkv=w.z(M, 3 * D, BF), lse=w.v(S * H * L),
+                             attn=w.z(M, D, BF), x_mid=w.z(M, D), h2=w.z(M, D, BF), mean2=w.v(M), rstd2=w.v(M),
+                             u=w.z(M, Fd, BF) if train else None, g=w.z(M, Fd, BF)))
+        ws["acts"] = acts
+        ws["hp"], ws["hmean"], ws["hrstd"], ws["tokens"] = w.z(M, D, BF), w.v(M), w.v(M), w.z(M, O)
+        ws["embed_a"] = fill(_lib.SigEmbedActs, patches=ws["patches"], tok=ws["tok"], pre_ln=ws["pre_ln"], mean=ws["emean"],
+                             rstd=ws["erstd"], x0=ws["x"][0])
+        ws["block_a"] = []
+        for i in range(self.layers):
+            a = acts[i if train else 0]
+            xin, xout = (ws["x"][i], ws["x"][i + 1]) if train else (ws["x"][i & 1], ws["x"][(i + 1) & 1])
+            ws["block_a"].append(fill(_lib.SigBlockActs, x_in=xin, x_out=xout, **a))
+        xl = ws["x"][self.layers] if train else ws["x"][self.layers & 1]
+        ws["head_a"] = fill(_lib.SigHeadActs, x=xl, hp=ws["hp"], mean=ws["hmean"], rstd=ws["hrstd"], tokens=ws["tokens"])
+        if train:
+            ws["du"], ws["dh"], ws["dqkv"] = w.z(M, Fd, BF), w.z(M, D, BF), w.z(M, 3 * D, BF)
+            ws["dx_mid"], ws["dx_mid_b"], ws["dx"], ws["dx_b"] = w.z(M, D), w.z(M, D, BF), w.z(M, D), w.z(M, D, BF)
+            ws["dtokens"], ws["dtok_b"] = w.z(M, O), w.z(M, O, BF)
+            ws["dpre"], ws["dtok_e"] = w.z(M, D), w.z(Mt, D, BF)
+            ws["scratch"] = fill(_lib.SigBlockScratch, du=ws["du"], dh=ws["dh"], dqkv=ws["dqkv"], dx_mid=ws["dx_mid"],
+                                 dx_mid_b=ws["dx_mid_b"])
+        ws["bytes"] = w.bytes
+        return ws
+
+    def _get_ws(self, pool, key, make):
+        free = pool.setdefault(key, [])
+        return free.pop() if free else make()
+
+    def vit_forward(self, imgs: List[torch.Tensor], cam: Optional[torch.Tensor], train: bool):
+        B = imgs[0].shape[0]
+        S = len(imgs) * B
+        ws = self._get_ws(self._vit_ws, (S, B, train), lambda: self._alloc_vit(S, B, train))
+        for i, im in enumerate(imgs):
+            if im.shape[1:] != (3, *self.img_hw):
+                raise ValueError(f"expected images [B,3,{self.img_hw[0]},{self.img_hw[1]}], got {tuple(im.shape)}")
+            ws["img"][i * B:(i + 1) * B].copy_(im)
+        ws["cam"] = cam
+        st = _stream()
+        d = ref(ws["dims"])
+        _lib.call("sig_embed_fwd", d, ref(self.embed_p), ref(ws["embed_a"]), ws["img"].data_ptr(),
+                  None if cam is None else cam.data_ptr(), self.img_hw[0], self.img_hw[1], self.patch, st)
+        for i in range(self.layers):
+            _lib.call("sig_block_fwd", d, ref(self.block_p[i]), ref(ws["block_a"][i]), st)
+        _lib.call("sig_head_fwd", d, ref(self.head_p), ref(ws["head_a"]), st)
+        return ws
+
+    def vit_backward(self, ws, dtokens: torch.Tensor):
+        """dtokens [S,L,out] -> accumulates every ViT parameter gradient into flat.grad."""
+        M, st, d = ws["M"], _stream(), ref(ws["dims"])
+        ws["dtokens"][:M].copy_(dtokens.reshape(M, self.out_dim))
+        _lib.call("sig_head_bwd", d, ref(self.head_p), ref(ws["head_a"]), ref(self.head_g), ws["dtokens"].data_ptr(),
+                  ws["dtok_b"].data_ptr(), ws["dh"].data_ptr(), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(), st)
+        for i in reversed(range(self.layers)):
+            _lib.call("sig_block_bwd", d, ref(self.block_p[i]), ref(ws["block_a"][i]), ref(self.block_g[i]),
+                      ref(ws["scratch"]), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(), ws["dx"].data_ptr(),
+                      ws["dx_b"].data_ptr(), st)
+            if self.on_block_grads_ready is not None:
+                self.on_block_grads_ready(i)
+        cam = ws["cam"]
+        _lib.call("sig_embed_bwd", d, ref(self.embed_p), ref(ws["embed_a"]), ref(self.embed_g), ws["dx"].data_ptr(),
+                  ws["dpre"].data_ptr(), ws["dtok_e"].data_ptr(), None if cam is None else cam.data_ptr(), self.patch, st)
+
+    on_block_grads_ready = None  # hook for the data-parallel reducer (signal_amd/parallel)
+
+    def release_vit(self, ws):
+        self._vit_ws[(ws["S"], ws["B"], ws["train"])].append(ws)
+
+    # ------------------------------------------------------------------ SIM
+    def _alloc_sim(self, B, train):
+        dev, L = self.flat.device, self.L
+        Lp, d = L - 1, 512
+        Mq, Mk = 3 * B, 3 * B * Lp
+        w = _Ws(dev)
+        ws = {"B": B, "train": train}
+        a = dict(qprime=w.v(B * 3 * d), cconst=w.v(B * 3), intra=w.v(B * 3 * Lp), inter=w.v(B * 9 * Lp),
+                 mask_f=w.v(3 * B * Lp), mask_u8=None, sel=w.z(Mk, d, BF), cls_b=w.z(Mq, d, BF), cls_f=w.z(Mq, d),
+                 qh=w.z(Mq, d), kv=w.z(Mk, 2 * d, BF), probs=w.v(B * 24 * 3 * Lp), ao=w.z(Mq, d, BF), y=w.z(Mq, d),
+                 z1=w.z(Mq, d), z1_b=w.z(Mq, d, BF), mean1=w.v(Mq), rstd1=w.v(Mq), f1_pre=w.z(Mq, 2 * d, BF),
+                 f1=w.z(Mq, 2 * d, BF), y2=w.z(Mq, d), mean2=w.v(Mq), rstd2=w.v(Mq), out=w.z(Mq, d))
+        ws["t"] = a
+        ws["acts"] = fill(_lib.SigSimActs, **a)
+        if train:
+            s = dict(dy2=w.z(Mq, d), dy2_b=w.z(Mq, d, BF), df1=w.z(Mq, 2 * d, BF), dz1=w.z(Mq, d), dy=w.z(Mq, d),
+                     dy_b=w.z(Mq, d, BF), dao=w.z(Mq, d), dqh=w.z(Mq, d), dqh_b=w.z(Mq, d, BF), dkv=w.z(Mk, 2 * d, BF),
+                     dsel=w.z(Mk, d, BF), dcls=w.z(Mq, d))
+            ws["s"] = s
+            ws["scratch"] = fill(_lib.SigSimScratch, **s)
+            ws["dout"] = w.z(Mq, d)
+        return ws
+
+    def sim_forward(self, tokens: torch.Tensor, B: int, train: bool, select_only: bool = False):
+        ws = self._get_ws(self._sim_ws, (B, train), lambda: self._alloc_sim(B, train))
+        name = "sig_sim_select" if select_only else "sig_sim_fwd"
+        _lib.call(name, tokens.data_ptr(), B, self.L, ref(self.sim_p), ref(ws["acts"]), _stream())
+        return ws
+
+    def sim_backward(self, ws, dout: torch.Tensor, dtokens: torch.Tensor):
+        B = ws["B"]
+        ws["dout"][:3 * B].copy_(dout.reshape(3 * B, 512))
+        _lib.call("sig_sim_bwd", ws["dout"].data_ptr(), B, self.L, ref(self.sim_p), ref(ws["acts"]), ref(self.sim_g),
+                  ref(ws["scratch"]), dtokens.data_ptr(), _stream())
+
+    def release_sim(self, ws):
+        self._sim_ws[(ws["B"], ws["train"])].append(ws)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# autograd plumbing
+# ---------------------------------------------------------------------------------------------------------
+class BackboneFn(torch.autograd.Function):
+    """tokens[S,L,out] = ViT(images); parameters are inputs so autograd routes the gradients the HIP
+    backward accumulated in FlatParams.grad to each Parameter's .grad."""
+
+    @staticmethod
+    def forward(ctx, hip: HipPath, cam, n_img, *args):
+        imgs, params = args[:n_img], args[n_img:]
+        train = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        ws = hip.vit_forward(list(imgs), cam, train)
+        ctx.hip, ctx.ws, ctx.n_img, ctx.train = hip, ws, n_img, train
+        M = ws["M"]
+        tokens = ws["tokens"][:M].view(ws["S"], hip.L, hip.out_dim)
+        if not train:
+            out = tokens.clone()
+            hip.release_vit(ws)
+            return out
+        return tokens.clone()
+
+    @staticmethod
+    def backward(ctx, dtokens):
+        hip, ws = ctx.hip, ctx.ws
+        hip.zero_grads_of("clip_vision_encoder.")
+        hip.vit_backward(ws, dtokens.contiguous())
+        grads = hip.grads_of("clip_vision_encoder.", hip.vit_param_names)
+        hip.release_vit(ws)
+        return (None, None, None) + (None,) * ctx.n_img + grads
+
+
+class SimFn(torch.autograd.Function):
+    """vars_total[B,1536] = SIM(tokens) (useA.py:454-476); masks are constants (no gradient path)."""
+
+    @staticmethod
+    def forward(ctx, hip: HipPath, B, tokens, *params):
+        train = (tokens.requires_grad or any(p.requires_grad for p in params)) and torch.is_grad_enabled()
+        tok = tokens.contiguous()   # read row-wise only, so it needs no row padding
+        ws = hip.sim_forward(tok, B, train)
+        ctx.hip, ctx.ws, ctx.B, ctx.shape = hip, ws, B, tokens.shape
+        out = ws["t"]["out"][:3 * B].reshape(B, 3 * 512).clone()
+        mask = ws["t"]["mask_f"].view(3, B, hip.L - 1).clone()
+        ctx.mark_non_differentiable(mask)
+        if not train:
+            hip.release_sim(ws)
+        return out, mask
+
+    @staticmethod
+    def backward(ctx, dout, _dmask):
+        hip, ws = ctx.hip, ctx.ws
+        hip.zero_grads_of("SIM.modal_interactive.")
+        dtokens = torch.zeros(ctx.shape, dtype=F32, device=dout.device)
+        hip.sim_backward(ws, dout.contiguous(), dtokens)
+        grads = hip.grads_of("SIM.modal_interactive.", hip.sim_param_names)
+        hip.release_sim(ws)
+        return (None, None, dtokens) + grads

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 # epilogue ids of sig_gemm_nt (include/signal_hip.h)
-F32, BF16, BIAS_F32, BIAS_BF16, BIAS_RES_F32, BIAS_GELU_BF16, DGELU_BF16 = range(7)
+F32, BF16, BIAS_F32, BIAS_BF16, BIAS_RES_F32, BIAS_GELU_BF16, DGELU_BF16, BIAS_GELUERF_BF16, DGELUERF_BF16, RES_F32 = range(10)
 
 ROW_PAD = 128
 
@@ -53,7 +53,7 @@ def gemm_nt(a: torch.Tensor, bt: torch.Tensor, m: int, epilogue: int, out: torch
         raise ValueError(f"gemm_nt: K mismatch {a.shape[1]} vs {k}")
     if a.shape[0] < pad_rows(m):
         raise ValueError(f"gemm_nt: a has {a.shape[0]} rows, needs {pad_rows(m)} (row padding)")
-    want = torch.float32 if epilogue in (F32, BIAS_F32, BIAS_RES_F32) else torch.bfloat16
+    want = torch.float32 if epilogue in (F32, BIAS_F32, BIAS_RES_F32, RES_F32) else torch.bfloat16
     _chk(out, want, "gemm_nt.out")
     if out.shape[0] < m or out.shape[1] != n:
         raise ValueError(f"gemm_nt: out shape {tuple(out.shape)} does not hold [{m},{n}]")
@@ -192,5 +192,5 @@ def embed_assemble(tok, cls_emb, pos, cv_embed, cam, sie_coe, ln_w, ln_b, x, pre
 
 
 def embed_bwd(d_pre, dtok_f32, dtok_bf16, dcls, dpos, dcv, cam, sie_coe, s, b, l, d):
-    _lib.call("sig_embed_bwd", d_pre.data_ptr(), _ptr(dtok_f32), _ptr(dtok_bf16), dcls.data_ptr(), dpos.data_ptr(),
+    _lib.call("sig_embed_assemble_bwd", d_pre.data_ptr(), _ptr(dtok_f32), _ptr(dtok_bf16), dcls.data_ptr(), dpos.data_ptr(),
               _ptr(dcv), _ptr(cam), float(sie_coe), s, b, l, d, _stream())
