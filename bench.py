@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RGB+NIR+TIR triplets per second at B=64 per GPU on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fwd_sim|train] [--batch 64]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic triplets already resident in HBM:
+  fwd_sim : BASELINE.json configs[1] -- three-stream ViT-B/16 forward + SIM (token selection + interaction)
+  train   : BASELINE.json configs[2] -- full Signal train step (forward, SIM+GAM+LAM, ID+triplet loss, backward,
+            Adam), data-parallel over the ranks with gradients all-reduced over RCCL
+Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel (the c_fc GEMM, M=24768 N=3072 K=768 with the
+fused bias+QuickGELU epilogue) timed live with HIP events on its launch stream during the timed steps;
+`cpu_baseline` = the CPU oracle (oracle/signal_ref.py, a port of the reference's PyTorch CPU path) on this
+box's host cores on a bounded sample of the same workload."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("SIGNAL_BENCH_WORKLOAD", "fwd_sim"), choices=["fwd_sim", "train"])
+    ap.add_argument("--batch", type=int, default=64, help="triplets per GPU (metric is quoted at 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(dev, workload):
+    from signal_amd.config import get_cfg_defaults
+    from signal_amd.modeling import make_frame
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "RGBNT201", "Signal.yml"))
+    cfg.freeze()
+    torch.manual_seed(1234)
+    model = make_frame(cfg, num_class=171, camera_num=4, view_num=0).to(dev)
+    return cfg, model
+
+
+def synthetic(cfg, B, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    H, W = cfg.INPUT.SIZE_TRAIN
+    img = {m: torch.randn(B, 3, H, W, generator=g).to(dev) for m in ("RGB", "NI", "TI")}
+    k = cfg.DATALOADER.NUM_INSTANCE
+    vid = (torch.arange(B) // k).to(dev)
+    cam = torch.randint(0, 4, (B,), generator=g).to(dev)
+    return img, vid, cam
+
+
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask, then the cgroup CPU quota, capped at the 16-core
+    share a one-GPU box grants (os.cpu_count() reports the whole 256-thread host there)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("SIGNAL_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(workload, budget_s=15.0):
+    """CPU oracle on the host cores, bounded sample: B=8 triplets (configs[0] of BASELINE.json)."""
+    from oracle import signal_ref as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ocfg = O.rgbnt201_config(num_instance=4)
+    sd = O.init_state_dict(ocfg, seed=1234, head_scale=30.0)
+    img, vid, cam = O.synthetic_batch(ocfg, 8, seed=1234)
+    if workload == "train":
+        for k, v in sd.items():
+            if v.is_floating_point() and "running_" not in k:
+                v.requires_grad_(True)
+        params = [v for v in sd.values() if v.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-5)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = O.train_loss(sd, ocfg, img, vid, cam)
+            loss.backward()
+            opt.step()
+        what = "oracle train step (fwd+SIM+GAM+LAM+ReID loss, bwd, Adam), fp32"
+    else:
+        def step():
+            with torch.no_grad():
+                O.signal_forward_infer(sd, ocfg, img, cam)
+        what = "oracle three-stream ViT-B/16 forward + SIM, fp32"
+    step()  # warm-up (allocator, thread pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": round(8 * n / el, 3), "unit": "triplets/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of B=8 synthetic 256x128 triplets, {what}, torch CPU {torch.get_num_threads()} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (signal_amd has no CPU path)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    from signal_amd import _lib, ops
+
+    cfg, model = build_model(dev, args.workload)
+    B = args.batch
+    img, vid, cam = synthetic(cfg, B, dev, 1234 + rank)
+
+    if args.workload == "fwd_sim":
+        def step():
+            with torch.no_grad():
+                return model(img, cam_label=cam, training=False)
+        parallelism = f"dp{world} (independent shards, no collective)"
+    else:
+        from signal_amd.engine.trainer import TrainStep
+        ts = TrainStep(cfg, model, num_classes=171, world_size=world)
+
+        def step():
+            return ts.step(img, vid, cam)
+        parallelism = f"dp{world} (RCCL all-reduce of gradients overlapped with backward)"
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    D, Fd = model.hip.D, model.hip.F
+    _lib.call("sig_prof_begin", ops.BIAS_GELU_BF16, Fd, D, 12 * args.steps + 8)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    ms, n, fl = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+    _lib.call("sig_prof_end", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    ach = fl.value / (ms.value * 1e-3) / 1e12 if n.value else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("gemm_nt_c_fc_bytes_per_launch")
+    out = {
+        "metric": "images/sec (RGB+NIR+TIR triplets) at B=64/GPU",
+        "value": round(world * B * args.steps / el, 2), "unit": "triplets/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": {"fwd_sim": "configs[1]: three-stream ViT-B/16 forward + SIM, RGBNT201 256x128, random init",
+                                "train": "configs[2]: full Signal (SIM+GAM+LAM) train step, RGBNT201 256x128, random init"}[args.workload],
+                   "batch_per_gpu": B, "global_batch": B * world, "tokens_per_image": 129, "parallelism": parallelism},
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<BIAS_GELU_BF16> (c_fc, M=%d N=%d K=%d)" % (3 * B * 129, Fd, D),
+                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                     "launches": n.value, "avg_us": round(ms.value / max(n.value, 1) * 1e3, 2)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

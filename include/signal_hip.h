@@ -26,6 +26,13 @@ extern "C" {
 const char* sig_last_error(void);
 int sig_version(void);
 
+/* Measurement aid (bench.py roofline leg): bracket every sig_gemm_nt launch of ONE shape (epilogue, N, K)
+ * with HIP events on its own stream, from sig_prof_begin until sig_prof_end; sig_prof_end waits for the
+ * recorded events (host-synchronising: call it outside any timed region) and returns the summed kernel
+ * time, the number of launches and their algorithmic FLOPs (2*M*N*K each). */
+int sig_prof_begin(int epilogue, int N, int K, int max_launches);
+int sig_prof_end(double* total_ms, int* launches, double* flops);
+
 /* ---- epilogues of sig_gemm_nt ---------------------------------------------------------------- */
 enum {
     SIG_GEMM_F32 = 0,           /* out f32  = acc                                   */

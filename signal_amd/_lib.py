@@ -12,6 +12,8 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 # name -> argtypes; mirrors include/signal_hip.h one to one (tests check the export list against the header)
 SIGNATURES = {
+    "sig_prof_begin": [_i, _i, _i, _i],
+    "sig_prof_end": [_vp, _vp, _vp],
     "sig_gemm_nt": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp],
     "sig_gemm_tn": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "sig_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],

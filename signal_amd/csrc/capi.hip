@@ -25,12 +25,14 @@ extern "C" {
 
 const char* sig_last_error(void) { return g_err; }
 int sig_version(void) { return SIG_ABI_VERSION; }
+int sig_prof_begin(int epilogue, int N, int K, int max_launches) { return sig_prof_begin_impl(epilogue, N, K, max_launches); }
+int sig_prof_end(double* total_ms, int* launches, double* flops) { return sig_prof_end_impl(total_ms, launches, flops); }
 
 int sig_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, int epilogue, void* out,
                 int ldo, const float* bias, const float* res, int ldr, void* aux, int ldaux, void* stream) {
     SigGemmNT p;
     p.A = A; p.Bt = Bt; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
-    p.out = out; p.ldo = ldo; p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
+    p.out = out; p.ldo = ldo; p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0;
     return sig_launch_gemm_nt(p, epilogue, (hipStream_t)stream);
 }
 

@@ -33,9 +33,12 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tn = p.N >> 7;
+    // tile order: blocks of one XCD get a contiguous range of a BAND-major order (band = wb column tiles whose
+    // weight rows, wb*128*K*2 B <= ~2.4 MB, stay resident in that XCD's 4 MB L2 while it sweeps the rows)
+    const int tn = p.N >> 7, tm = gridDim.x / tn, wb = p.band;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = id / tn, tile_n = id - tile_m * tn;
+    const int per = tm * wb, bnd = id / per, rr = id - bnd * per;
+    const int tile_m = rr / wb, tile_n = bnd * wb + (rr - tile_m * wb);
     const int m0 = tile_m << 7, n0 = tile_n << 7;
 
     // ---- staging: wave w moves pieces w*4..w*4+3 (8 rows x 128 B each) of A and of Bt ----
@@ -140,15 +143,73 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     }
 }
 
+// ---- live timing of one GEMM shape (bench.py's roofline leg): HIP events on the launch stream ----
+#include <vector>
+static struct {
+    bool on = false;
+    int epi = -1, N = 0, K = 0;
+    size_t used = 0;
+    double flops = 0;
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+} g_prof;
+
+int sig_prof_begin_impl(int epi, int N, int K, int max_launches) {
+    SIG_CHECK_ARG(max_launches > 0 && max_launches <= 65536, "prof_begin: max_launches out of range");
+    while (g_prof.ev.size() < (size_t)2 * max_launches) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            sig_set_error("prof_begin: hipEventCreate failed");
+            return 2;
+        }
+        g_prof.ev.push_back(e);
+    }
+    g_prof.on = true; g_prof.epi = epi; g_prof.N = N; g_prof.K = K; g_prof.used = 0; g_prof.flops = 0;
+    return 0;
+}
+int sig_prof_end_impl(double* total_ms, int* launches, double* flops) {
+    g_prof.on = false;
+    double ms = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) {
+            sig_set_error("prof_end: hipEventSynchronize failed");
+            return 2;
+        }
+        float t = 0;
+        (void)hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int)(g_prof.used / 2);
+    if (flops) *flops = g_prof.flops;
+    return 0;
+}
+
+static int choose_band(int tn, int K) {
+    int wmax = (int)(2400000LL / (256LL * K));
+    if (wmax < 1) wmax = 1;
+    for (int nb = 1; nb <= tn; ++nb)
+        if (tn % nb == 0 && tn / nb <= wmax) return tn / nb;
+    return 1;
+}
+
 template <int EPI>
-static int launch_nt(const SigGemmNT& p, hipStream_t st) {
+static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
+    SigGemmNT p = p_in;
+    p.band = choose_band(p.N >> 7, p.K);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_done = true;
     }
     const int tiles = ((p.M + 127) >> 7) * (p.N >> 7);
+    const bool timed = g_prof.on && g_prof.epi == EPI && g_prof.N == p.N && g_prof.K == p.K && g_prof.used + 2 <= g_prof.ev.size();
+    if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
     hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tiles), dim3(256), 65536, st, p);
+    if (timed) {
+        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+        g_prof.used += 2;
+        g_prof.flops += 2.0 * p.M * p.N * p.K;
+    }
     SIG_CHECK_LAUNCH("gemm_nt");
     return 0;
 }

@@ -28,8 +28,11 @@ struct SigGemmNT {
     int ldr;
     void* aux;         // bf16 [M, ldaux]
     int ldaux;
+    int band;          // column tiles per L2-resident weight band (filled by the launcher)
 };
 int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st);
+int sig_prof_begin_impl(int epi, int N, int K, int max_launches);
+int sig_prof_end_impl(double* total_ms, int* launches, double* flops);
 
 struct SigGemmTN {
     const bf16_t* P;  // [Mr, ldp], columns I

@@ -25,7 +25,7 @@ static SigGemmNT nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, 
                     const float* bias = nullptr, const float* res = nullptr, int ldr = 0, void* aux = nullptr, int ldaux = 0) {
     SigGemmNT p;
     p.A = A; p.lda = lda; p.Bt = Bt; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo;
-    p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
+    p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0;
     return p;
 }
 static SigGemmTN tn(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int Mr, int I, int J, float* out, int ldo) {
