@@ -232,6 +232,58 @@ int sig_xattn_fwd(const float* q, const uint16_t* kv, int B, int NK, uint16_t* o
 int sig_xattn_bwd(const float* q, const uint16_t* kv, const float* probs, const float* dout, int B, int NK, float* dq,
                   uint16_t* dkv, void* stream);
 
+/* ================================================================================================
+ * GAM -- AlignmentM.Cls_Align (modeling/AddModule/useB.py:76-126) with volume_computation3
+ * (utils/volume.py:14-62) in closed form: mean-pool the patch tokens per modality, L2-normalise,
+ * V[i,j] = sqrt|det Gram(r_i, n_j, t_j)|, loss = (CE(-V/T, diag, ls=.1) + CE(-V^T/T, diag, ls=.1)) / 2.
+ * Backward is analytic; where det == 0 the reference produces NaN gradients, this uses a zero sub-gradient.
+ * ================================================================================================ */
+typedef struct SigGamActs {
+    float *fh, *nrm;          /* [3,B,512] normalised pooled features, [3B] their pre-normalisation norms */
+    float *lv, *la, *vec;     /* [B,B] r.n, [B,B] r.t, [4B] (ll | vv | va | aa) */
+    float* coef;              /* [2*B*B + 4*B + 1] backward coefficients */
+    float* loss;              /* [1] */
+} SigGamActs;
+int sig_gam_fwd(const float* tokens, int B, int L, const float* contra_temp, const SigGamActs* a, void* stream);
+/* dloss: device scalar (upstream gradient); dtokens f32 [S*L,512] and d_contra_temp [1] are ACCUMULATED into */
+int sig_gam_bwd(int B, int L, const SigGamActs* a, const float* dloss, float* dtokens, float* d_contra_temp, void* stream);
+
+/* ================================================================================================
+ * LAM -- AlignmentM.patch_Align (useB.py:128-167) with DA_sample (DAS.py:107-165), one parameter set per
+ * modality (DAS_r, DAS_n, DAS_t).  The patch tokens of a modality, viewed as an [h, w] map of 512-vectors:
+ * q = proj_q(x); o = conv_offset(q) (1x1 -> GELU -> depthwise 4x4 stride 4 -> GELU -> 1x1 to one channel);
+ * p = clamp(ref + 2 tanh(o) / (n-1)) on both axes; bilinear sample of x at p (align_corners, zero padding);
+ * loss = mean of the three pairwise MSEs of the sampled maps.
+ * ================================================================================================ */
+typedef struct SigDasParams {
+    const uint16_t *w_q, *w_0;      /* bf16 [512,512] proj_q.weight, conv_offset.0.weight ([out,in,1,1])   */
+    const uint16_t *wt_q, *wt_0;    /* transposes (backward only)                                          */
+    const float *b_q, *b_0;         /* [512]                                                               */
+    const float *wd, *bd, *w4;      /* conv_offset.2.weight [512,1,4,4], .2.bias [512], conv_offset.4.weight [1,512,1,1] */
+} SigDasParams;
+typedef struct SigDasGrads { float *w_q, *w_0, *b_q, *b_0, *wd, *bd, *w4; } SigDasGrads;
+typedef struct SigLamActs {         /* leading [3] = modality; R = B*(L-1) rows padded to 128 */
+    uint16_t *xb, *q, *a1, *a1pre;  /* bf16 [3][R,512] */
+    float *a2pre, *offs, *samp;     /* f32 [3][B,P,512], [3][B,P,3] (o, p_y, p_x), [3][B,P,512] ; P = (h/4)*(w/4) <= 8 */
+    float* loss;                    /* [1] */
+} SigLamActs;
+typedef struct SigLamScratch { uint16_t *da1pre, *dq; float* dx; } SigLamScratch;   /* [R,512] each, pad rows zero */
+int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, const SigDasParams* p3, const SigLamActs* a, void* stream);
+int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, const SigDasParams* p3, const SigDasGrads* g3,
+                const SigLamActs* a, const SigLamScratch* s, const float* dloss, float* dtokens, void* stream);
+
+/* ================================================================================================
+ * Optimizer step of the train loop (engine/processor.py:259-261 with solver/make_optimizer.py:4-45):
+ * torch.optim.Adam semantics (L2 weight decay added to the gradient, bias correction, eps outside the sqrt)
+ * over a flat f32 parameter buffer cut into nseg segments (one per parameter, the reference's one param
+ * group per parameter) with per-segment lr and weight decay.  seg_end[k] = end offset (elements) of segment
+ * k; grad_scale multiplies the gradient first (1/world_size after a sum all-reduce); p_bf16 (may be NULL)
+ * receives the refreshed bf16 GEMM operands.
+ * ================================================================================================ */
+int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, const int* seg_end,
+                  const float* seg_lr, const float* seg_wd, int nseg, float beta1, float beta2, float eps, int step,
+                  float grad_scale, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,7 +65,18 @@ SigSimGrads = _struct("SigSimGrads", ["w_q", "w_kv", "w_o", "w_f1", "w_f2", "b_q
                                        "n1_w", "n1_b", "n2_w", "n2_b"])
 SigSimScratch = _struct("SigSimScratch", ["dy2", "dy2_b", "df1", "dz1", "dy", "dy_b", "dao", "dqh", "dqh_b", "dkv", "dsel", "dcls"])
 
+SigGamActs = _struct("SigGamActs", ["fh", "nrm", "lv", "la", "vec", "coef", "loss"])
+SigDasParams = _struct("SigDasParams", ["w_q", "w_0", "wt_q", "wt_0", "b_q", "b_0", "wd", "bd", "w4"])
+SigDasGrads = _struct("SigDasGrads", ["w_q", "w_0", "b_q", "b_0", "wd", "bd", "w4"])
+SigLamActs = _struct("SigLamActs", ["xb", "q", "a1", "a1pre", "a2pre", "offs", "samp", "loss"])
+SigLamScratch = _struct("SigLamScratch", ["da1pre", "dq", "dx"])
+
 SIGNATURES.update({
+    "sig_adam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _f, _sz, _vp],
+    "sig_gam_fwd": [_vp, _i, _i, _vp, _vp, _vp],
+    "sig_gam_bwd": [_i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sig_lam_fwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "sig_lam_bwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sig_embed_assemble_bwd": SIGNATURES.pop("sig_embed_bwd"),
     "sig_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sig_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],

@@ -95,4 +95,11 @@ int sig_embed_assemble_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dto
                                 cam_label, sie_coe, S, B, L, D, (hipStream_t)stream);
 }
 
+int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, const int* seg_end, const float* seg_lr,
+                  const float* seg_wd, int nseg, float beta1, float beta2, float eps, int step, float grad_scale, size_t n,
+                  void* stream) {
+    return sig_launch_adam(p, g, m, v, p_bf16, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, step, grad_scale, n,
+                           (hipStream_t)stream);
+}
+
 }  // extern "C"

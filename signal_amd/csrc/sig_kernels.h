@@ -80,3 +80,22 @@ int sig_launch_xattn_bwd(const float* q, const bf16_t* kv, const float* probs, c
 
 int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
                         int S, int L, int H, hipStream_t st);
+
+// ---- GAM / LAM (align.hip) ------------------------------------------------------------------------------
+int sig_launch_gam_fwd(const float* tokens, int B, int L, const float* temp, float* fh, float* nrm, float* lv, float* la,
+                       float* vec, float* coef, float* loss, hipStream_t st);
+int sig_launch_gam_bwd(const float* fh, const float* nrm, const float* coef, const float* dloss, int B, int L, float* dtokens,
+                       float* dtemp, hipStream_t st);
+int sig_launch_lam_gather(const float* tokens, int B, int L, bf16_t* xb, size_t xstride, hipStream_t st);
+int sig_launch_lam_scatter_add(const float* src, int m, int B, int L, float* dtokens, hipStream_t st);
+int sig_launch_lam_tail_fwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const float* wd,
+                            const float* bd, const float* w4, float* a2pre, float* offs, float* samp, hipStream_t st);
+int sig_launch_lam_loss(const float* samp, size_t n, float* loss, hipStream_t st);
+int sig_launch_lam_tail_bwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre,
+                            const float* wd, const float* w4, const float* a2pre, const float* offs, const float* samp_all,
+                            size_t nsamp, const float* dloss, bf16_t* da1pre, float* dwd, float* dbd, float* dw4, float* dtokens,
+                            hipStream_t st);
+
+// ---- optimizer (optim.hip) ------------------------------------------------------------------------------
+int sig_launch_adam(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, const int* seg_end, const float* seg_lr,
+                    const float* seg_wd, int nseg, float b1, float b2, float eps, int step, float gscale, size_t n, hipStream_t st);

@@ -223,6 +223,64 @@ int sig_sim_bwd(const float* dout, int B, int L, const SigSimParams* p, const Si
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// GAM / LAM
+// ------------------------------------------------------------------------------------------------
+int sig_gam_fwd(const float* tokens, int B, int L, const float* contra_temp, const SigGamActs* a, void* stream) {
+    SIG_CHECK_ARG(tokens && contra_temp && a, "gam_fwd: null argument");
+    return sig_launch_gam_fwd(tokens, B, L, contra_temp, a->fh, a->nrm, a->lv, a->la, a->vec, a->coef, a->loss, (hipStream_t)stream);
+}
+int sig_gam_bwd(int B, int L, const SigGamActs* a, const float* dloss, float* dtokens, float* d_contra_temp, void* stream) {
+    SIG_CHECK_ARG(a && dloss && dtokens, "gam_bwd: null argument");
+    return sig_launch_gam_bwd(a->fh, a->nrm, a->coef, dloss, B, L, dtokens, d_contra_temp, (hipStream_t)stream);
+}
+
+int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, const SigDasParams* p3, const SigLamActs* a, void* stream) {
+    SIG_CHECK_ARG(tokens && p3 && a, "lam_fwd: null argument");
+    SIG_CHECK_ARG(a->xb && a->q && a->a1 && a->a1pre && a->a2pre && a->offs && a->samp && a->loss, "lam_fwd: activation buffer missing");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = B * (L - 1), Rp = pad128(R), d = 512, P = (h / 4) * (w / 4);
+    RUN(sig_launch_lam_gather(tokens, B, L, a->xb, (size_t)Rp, st));
+    for (int m = 0; m < 3; ++m) {
+        const SigDasParams* p = p3 + m;
+        const size_t o = (size_t)m * Rp * d;
+        RUN(sig_launch_gemm_nt(nt(a->xb + o, d, p->w_q, d, R, d, d, a->q + o, d, p->b_q), SIG_EPI_BIAS_BF16, st));
+        RUN(sig_launch_gemm_nt(nt(a->q + o, d, p->w_0, d, R, d, d, a->a1 + o, d, p->b_0, nullptr, 0, a->a1pre + o, d),
+                               SIG_EPI_BIAS_GELUERF_BF16, st));
+        RUN(sig_launch_lam_tail_fwd(tokens, m, B, L, h, w, a->a1 + o, p->wd, p->bd, p->w4, a->a2pre + (size_t)m * B * P * d,
+                                    a->offs + (size_t)m * B * P * 3, a->samp + (size_t)m * B * P * d, st));
+    }
+    RUN(sig_launch_lam_loss(a->samp, (size_t)B * P * d, a->loss, st));
+    return 0;
+}
+
+int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, const SigDasParams* p3, const SigDasGrads* g3,
+                const SigLamActs* a, const SigLamScratch* s, const float* dloss, float* dtokens, void* stream) {
+    SIG_CHECK_ARG(tokens && p3 && g3 && a && s && dloss && dtokens, "lam_bwd: null argument");
+    SIG_CHECK_ARG(s->da1pre && s->dq && s->dx, "lam_bwd: scratch missing");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = B * (L - 1), Rp = pad128(R), d = 512, P = (h / 4) * (w / 4);
+    const size_t nsamp = (size_t)B * P * d;
+    for (int m = 0; m < 3; ++m) {
+        const SigDasParams* p = p3 + m;
+        const SigDasGrads* g = g3 + m;
+        SIG_CHECK_ARG(p->wt_q && p->wt_0, "lam_bwd: transposed weights missing");
+        const size_t o = (size_t)m * Rp * d;
+        RUN(sig_launch_lam_tail_bwd(tokens, m, B, L, h, w, a->a1 + o, a->a1pre + o, p->wd, p->w4, a->a2pre + (size_t)m * nsamp,
+                                    a->offs + (size_t)m * B * P * 3, a->samp, nsamp, dloss, s->da1pre, g->wd, g->bd, g->w4, dtokens, st));
+        // conv_offset.0
+        RUN(sig_launch_gemm_nt(nt(s->da1pre, d, p->wt_0, d, R, d, d, s->dq, d), SIG_EPI_BF16, st));
+        RUN(sig_launch_gemm_tn(tn(s->da1pre, d, a->q + o, d, Rp, d, d, g->w_0, d), st));
+        RUN(sig_launch_colsum_bf16(s->da1pre, d, R, d, g->b_0, st));
+        // proj_q
+        RUN(sig_launch_gemm_nt(nt(s->dq, d, p->wt_q, d, R, d, d, s->dx, d), SIG_EPI_F32, st));
+        RUN(sig_launch_gemm_tn(tn(s->dq, d, a->xb + o, d, Rp, d, d, g->w_q, d), st));
+        RUN(sig_launch_colsum_bf16(s->dq, d, R, d, g->b_q, st));
+        RUN(sig_launch_lam_scatter_add(s->dx, m, B, L, dtokens, st));
+    }
+    return 0;
+}
+
 int sig_xattn_fwd(const float* q, const uint16_t* kv, int B, int NK, uint16_t* out, float* probs, void* stream) {
     return sig_launch_xattn_fwd(q, kv, B, NK, out, probs, (hipStream_t)stream);
 }

@@ -102,6 +102,8 @@ class HipPath:
         self.flat: Optional[FlatParams] = None
         self._vit_ws: Dict[tuple, list] = {}
         self._sim_ws: Dict[tuple, list] = {}
+        self._gam_ws: Dict[tuple, list] = {}
+        self._lam_ws: Dict[tuple, list] = {}
         enc = model.clip_vision_encoder
         b = enc.base
         self.D, self.H, self.layers, self.out_dim, self.patch = b.width, b.heads, b.layers, b.output_dim, b.patch
@@ -111,12 +113,9 @@ class HipPath:
 
     # ------------------------------------------------------------------ parameters
     def _hip_named_params(self) -> Dict[str, torch.nn.Parameter]:
-        m = self.model
-        out = {}
-        for n, p in m.named_parameters():
-            if n.startswith(("clip_vision_encoder.", "SIM.", "AlignM.")):
-                out[n] = p
-        return out
+        # every parameter lives in the flat buffer (the fused optimizer and the gradient reducer walk it);
+        # the HIP stages read the clip_vision_encoder. / SIM. / AlignM. groups
+        return dict(self.model.named_parameters())
 
     def prepare(self, device):
         """(Re)build flat storage if needed and refresh the bf16 operands when a parameter changed."""
@@ -130,8 +129,25 @@ class HipPath:
                 raise _lib.SignalHipError("model parameters are not on the input's device: call model.to(device) first")
             self.flat = FlatParams(named, device)
             self._build_structs()
+            if self.direct_grads:
+                self.enable_direct_grads()
         if self.flat.stale():
             self._pack()
+
+    direct_grads = False
+
+    def enable_direct_grads(self):
+        """Training-engine mode: every Parameter's .grad is a persistent view of flat.grad; the HIP backward
+        stages accumulate straight into it (no per-step clone), zeroing is one memset, the optimizer and the
+        data-parallel reducer work on the flat buffer."""
+        self.direct_grads = True
+        for n, p in self.flat.byname.items():
+            p.grad = self.flat.view(self.flat.grad, n)
+
+    def after_fused_step(self):
+        """The fused optimizer already refreshed flat.bf16; redo the transposed copies and mark versions."""
+        self._pack(cast=False)
+        self.flat._versions = tuple(p._version for p in self.flat.params)
 
     def _pk(self, name):      # bf16 view of a parameter (same layout as f32)
         return self.flat.view(self.flat.bf16, name)
@@ -231,10 +247,29 @@ class HipPath:
             self.sim_param_names = [n for n in fl.names if n.startswith(mi)]
             self._sim_in_w = inw
 
-    def _pack(self):
+        self.das_p = self.das_g = None
+        if "AlignM.contra_temp" in self._byname:
+            DP, DG = _lib.SigDasParams * 3, _lib.SigDasGrads * 3
+            ps, gs = [], []
+            for mch in "rnt":
+                a = f"AlignM.DAS_{mch}."
+                ps.append(fill(_lib.SigDasParams, w_q=self._pk(a + "proj_q.weight"), w_0=self._pk(a + "conv_offset.0.weight"),
+                               wt_q=T(a + "proj_q.weight", 512, 512), wt_0=T(a + "conv_offset.0.weight", 512, 512),
+                               b_q=self._p(a + "proj_q.bias"), b_0=self._p(a + "conv_offset.0.bias"),
+                               wd=self._p(a + "conv_offset.2.weight"), bd=self._p(a + "conv_offset.2.bias"),
+                               w4=self._p(a + "conv_offset.4.weight")))
+                gs.append(fill(_lib.SigDasGrads, w_q=self._g(a + "proj_q.weight"), w_0=self._g(a + "conv_offset.0.weight"),
+                               b_q=self._g(a + "proj_q.bias"), b_0=self._g(a + "conv_offset.0.bias"),
+                               wd=self._g(a + "conv_offset.2.weight"), bd=self._g(a + "conv_offset.2.bias"),
+                               w4=self._g(a + "conv_offset.4.weight")))
+            self.das_p, self.das_g = DP(*ps), DG(*gs)
+            self.das_param_names = [n for n in fl.names if n.startswith("AlignM.DAS_")]
+
+    def _pack(self, cast=True):
         """f32 -> bf16 for every parameter in one kernel, then the transposed copies."""
         fl, st = self.flat, _stream()
-        _lib.call("sig_cast_bf16", fl.data.data_ptr(), fl.bf16.data_ptr(), fl.total, st)
+        if cast:
+            _lib.call("sig_cast_bf16", fl.data.data_ptr(), fl.bf16.data_ptr(), fl.total, st)
         for name, t in self._transposed.items():
             src = self._byname[name].data
             r, c = (src.shape[0], src.numel() // src.shape[0])
@@ -366,6 +401,50 @@ class HipPath:
         self._sim_ws[(ws["B"], ws["train"])].append(ws)
 
 
+    # ------------------------------------------------------------------ GAM / LAM
+    def gam_forward(self, tokens, B):
+        def make():
+            w = _Ws(self.flat.device)
+            t = dict(fh=w.v(3 * B * 512), nrm=w.v(3 * B), lv=w.v(B * B), la=w.v(B * B), vec=w.v(4 * B),
+                     coef=w.v(2 * B * B + 4 * B + 1), loss=w.v(1))
+            return {"B": B, "t": t, "acts": fill(_lib.SigGamActs, **t)}
+        ws = self._get_ws(self._gam_ws, (B,), make)
+        temp = self.flat.byname["AlignM.contra_temp"].data
+        _lib.call("sig_gam_fwd", tokens.data_ptr(), B, self.L, temp.data_ptr(), ref(ws["acts"]), _stream())
+        return ws
+
+    def gam_backward(self, ws, dloss, dtokens):
+        _lib.call("sig_gam_bwd", ws["B"], self.L, ref(ws["acts"]), dloss.data_ptr(), dtokens.data_ptr(),
+                  self._g("AlignM.contra_temp").data_ptr(), _stream())
+
+    def lam_forward(self, tokens, B, train):
+        h, wd_ = self.model.h, self.model.w
+        P, R = (h // 4) * (wd_ // 4), B * (self.L - 1)
+
+        def make():
+            w = _Ws(self.flat.device)
+            Rp = pad_rows(R)
+            t = dict(xb=w.z(3 * Rp, 512, BF), q=w.z(3 * Rp, 512, BF), a1=w.z(3 * Rp, 512, BF), a1pre=w.z(3 * Rp, 512, BF),
+                     a2pre=w.v(3 * B * P * 512), offs=w.v(3 * B * P * 3), samp=w.v(3 * B * P * 512), loss=w.v(1))
+            ws = {"B": B, "train": train, "t": t, "acts": fill(_lib.SigLamActs, **t)}
+            if train:
+                s = dict(da1pre=w.z(R, 512, BF), dq=w.z(R, 512, BF), dx=w.z(R, 512))
+                ws["s"], ws["scratch"] = s, fill(_lib.SigLamScratch, **s)
+            return ws
+        ws = self._get_ws(self._lam_ws, (B, train), make)
+        _lib.call("sig_lam_fwd", tokens.data_ptr(), B, self.L, h, wd_, C_ptr(self.das_p), ref(ws["acts"]), _stream())
+        return ws
+
+    def lam_backward(self, ws, tokens, dloss, dtokens):
+        _lib.call("sig_lam_bwd", tokens.data_ptr(), ws["B"], self.L, self.model.h, self.model.w, C_ptr(self.das_p),
+                  C_ptr(self.das_g), ref(ws["acts"]), ref(ws["scratch"]), dloss.data_ptr(), dtokens.data_ptr(), _stream())
+
+
+def C_ptr(arr):
+    import ctypes
+    return ctypes.cast(arr, ctypes.c_void_p)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # autograd plumbing
 # ---------------------------------------------------------------------------------------------------------
@@ -376,7 +455,7 @@ class BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hip: HipPath, cam, n_img, *args):
         imgs, params = args[:n_img], args[n_img:]
-        train = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        train = any(ctx.needs_input_grad)     # grad mode is off inside forward(); this is what autograd will ask for
         ws = hip.vit_forward(list(imgs), cam, train)
         ctx.hip, ctx.ws, ctx.n_img, ctx.train = hip, ws, n_img, train
         M = ws["M"]
@@ -390,9 +469,13 @@ class BackboneFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dtokens):
         hip, ws = ctx.hip, ctx.ws
-        hip.zero_grads_of("clip_vision_encoder.")
-        hip.vit_backward(ws, dtokens.contiguous())
-        grads = hip.grads_of("clip_vision_encoder.", hip.vit_param_names)
+        if hip.direct_grads:
+            hip.vit_backward(ws, dtokens.contiguous())
+            grads = (None,) * len(hip.vit_param_names)
+        else:
+            hip.zero_grads_of("clip_vision_encoder.")
+            hip.vit_backward(ws, dtokens.contiguous())
+            grads = hip.grads_of("clip_vision_encoder.", hip.vit_param_names)
         hip.release_vit(ws)
         return (None, None, None) + (None,) * ctx.n_img + grads
 
@@ -402,7 +485,7 @@ class SimFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hip: HipPath, B, tokens, *params):
-        train = (tokens.requires_grad or any(p.requires_grad for p in params)) and torch.is_grad_enabled()
+        train = any(ctx.needs_input_grad)
         tok = tokens.contiguous()   # read row-wise only, so it needs no row padding
         ws = hip.sim_forward(tok, B, train)
         ctx.hip, ctx.ws, ctx.B, ctx.shape = hip, ws, B, tokens.shape
@@ -416,9 +499,67 @@ class SimFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dmask):
         hip, ws = ctx.hip, ctx.ws
-        hip.zero_grads_of("SIM.modal_interactive.")
         dtokens = torch.zeros(ctx.shape, dtype=F32, device=dout.device)
-        hip.sim_backward(ws, dout.contiguous(), dtokens)
-        grads = hip.grads_of("SIM.modal_interactive.", hip.sim_param_names)
+        if hip.direct_grads:
+            hip.sim_backward(ws, dout.contiguous(), dtokens)
+            grads = (None,) * len(hip.sim_param_names)
+        else:
+            hip.zero_grads_of("SIM.modal_interactive.")
+            hip.sim_backward(ws, dout.contiguous(), dtokens)
+            grads = hip.grads_of("SIM.modal_interactive.", hip.sim_param_names)
         hip.release_sim(ws)
+        return (None, None, dtokens) + grads
+
+
+class GamFn(torch.autograd.Function):
+    """loss_area = AlignmentM.Cls_Align(patches) (useB.py:76-126)."""
+
+    @staticmethod
+    def forward(ctx, hip: HipPath, B, tokens, contra_temp):
+        tok = tokens.contiguous()
+        ws = hip.gam_forward(tok, B)
+        ctx.hip, ctx.ws, ctx.shape = hip, ws, tokens.shape
+        return ws["t"]["loss"][0].clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        hip, ws = ctx.hip, ctx.ws
+        dtokens = torch.zeros(ctx.shape, dtype=F32, device=dloss.device)
+        if hip.direct_grads:
+            hip.gam_backward(ws, dloss.contiguous().reshape(1), dtokens)
+            dtemp = None
+        else:
+            hip._g("AlignM.contra_temp").zero_()
+            hip.gam_backward(ws, dloss.contiguous().reshape(1), dtokens)
+            dtemp = hip._g("AlignM.contra_temp").clone()
+        hip._gam_ws[(ws["B"],)].append(ws)
+        return None, None, dtokens, dtemp
+
+
+class LamFn(torch.autograd.Function):
+    """patch_loss = AlignmentM.patch_Align(patches) (useB.py:128-167)."""
+
+    @staticmethod
+    def forward(ctx, hip: HipPath, B, tokens, *params):
+        train = any(ctx.needs_input_grad)
+        tok = tokens.contiguous()
+        ws = hip.lam_forward(tok, B, train)
+        ctx.hip, ctx.ws, ctx.tok = hip, ws, tok
+        out = ws["t"]["loss"][0].clone()
+        if not train:
+            hip._lam_ws[(B, train)].append(ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dloss):
+        hip, ws = ctx.hip, ctx.ws
+        dtokens = torch.zeros(ctx.tok.shape, dtype=F32, device=dloss.device)
+        if hip.direct_grads:
+            hip.lam_backward(ws, ctx.tok, dloss.contiguous().reshape(1), dtokens)
+            grads = (None,) * len(hip.das_param_names)
+        else:
+            hip.zero_grads_of("AlignM.DAS_")
+            hip.lam_backward(ws, ctx.tok, dloss.contiguous().reshape(1), dtokens)
+            grads = hip.grads_of("AlignM.DAS_", hip.das_param_names)
+        hip._lam_ws[(ws["B"], ws["train"])].append(ws)
         return (None, None, dtokens) + grads

@@ -1,0 +1,69 @@
+"""Data-parallel gradient exchange: the reference wraps the model in
+DistributedDataParallel(find_unused_parameters=True); here the gradients already live in ONE flat f32 buffer,
+so the reducer is a bucket plan over that buffer -- one ~28 MB bucket per transformer block, issued as an
+asynchronous RCCL all-reduce (torch.distributed 'nccl' backend = RCCL over xGMI) the moment the block's
+backward has been enqueued, overlapping with the backward of the blocks below; the small remainder (embedding,
+head, SIM, AlignM, classifiers) goes last.  Sum all-reduce; the 1/world_size average is folded into the
+optimizer's grad_scale.  Gradient-less parameters (SIM.token_selection.*) are excluded statically instead of
+find_unused_parameters' per-step bitmap exchange."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def plan_buckets(names: Sequence[str], offsets: Dict[str, int], sizes: Dict[str, int], total: int,
+                 skip: Callable[[str], bool] = lambda n: False):
+    """-> (block_buckets {layer: (lo, hi)}, rest [(lo, hi), ...]) element ranges of the flat buffer.
+    A block bucket is the contiguous range of 'transformer.resblocks.<i>.' parameters; `rest` covers every other
+    non-skipped parameter, merged into maximal contiguous ranges."""
+    pad = lambda n: (n + 63) // 64 * 64
+    blocks: Dict[int, List[int]] = {}
+    other: List[Tuple[int, int]] = []
+    for n in names:
+        lo, hi = offsets[n], offsets[n] + pad(sizes[n])
+        if ".transformer.resblocks." in n:
+            i = int(n.split(".transformer.resblocks.")[1].split(".")[0])
+            b = blocks.setdefault(i, [lo, hi])
+            if lo != b[1] and lo != b[0]:
+                if lo < b[0] or lo > b[1]:
+                    raise RuntimeError(f"block {i} parameters are not contiguous in the flat buffer")
+            b[0], b[1] = min(b[0], lo), max(b[1], hi)
+        elif not skip(n):
+            if other and other[-1][1] == lo:
+                other[-1] = (other[-1][0], hi)
+            else:
+                other.append((lo, hi))
+    return {i: (b[0], b[1]) for i, b in blocks.items()}, other
+
+
+class GradReducer:
+    def __init__(self, flat_grad: torch.Tensor, block_buckets: Dict[int, Tuple[int, int]], rest: List[Tuple[int, int]],
+                 group=None):
+        self.g, self.blocks, self.rest, self.group = flat_grad, block_buckets, rest, group
+        self.pending = []
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def on_block_ready(self, layer: int):
+        """Call right after block `layer`'s backward was enqueued on the current stream."""
+        if self.world == 1 or layer not in self.blocks:
+            return
+        lo, hi = self.blocks[layer]
+        self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Reduce the remainder and make the current stream wait for every outstanding bucket."""
+        if self.world == 1:
+            return
+        for lo, hi in self.rest:
+            self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
+
+    def broadcast_params(self, flat_data: torch.Tensor, src: int = 0):
+        """Initial parameter sync (DDP construction broadcast)."""
+        if self.world > 1:
+            dist.broadcast(flat_data, src=src, group=self.group)
