@@ -1,0 +1,211 @@
+"""CPU-only checks (no GPU in the build container): the C-ABI library loads and exports every symbol the header
+declares, the host-side mirrors of the reference interface behave, and the data-parallel reducer is correct
+under a 2-rank gloo group."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import signal_ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "signal_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:const\s+char\*|int)\s+(sig_\w+)\s*\(", txt, flags=re.M)))
+
+
+def test_library_exports_every_header_symbol():
+    from signal_amd import _lib
+    lib = _lib.load()          # raises loudly when the .so is missing
+    syms = header_symbols()
+    assert len(syms) >= 30, syms
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/signal_hip.h but not exported"
+    # the ctypes table binds exactly the header's int-returning functions
+    bound = set(_lib.SIGNATURES) | {"sig_last_error", "sig_version"}
+    assert bound == set(syms), bound ^ set(syms)
+    assert lib.sig_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """Field order of the ctypes mirrors == field order of the C structs (all pointer-sized / int / float)."""
+    from signal_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "signal_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    for name in ["SigVitDims", "SigEmbedParams", "SigEmbedActs", "SigEmbedGrads", "SigBlockParams", "SigBlockActs",
+                 "SigBlockGrads", "SigBlockScratch", "SigHeadParams", "SigHeadActs", "SigHeadGrads", "SigSimParams",
+                 "SigSimActs", "SigSimGrads", "SigSimScratch", "SigGamActs", "SigDasParams", "SigDasGrads", "SigLamActs",
+                 "SigLamScratch"]:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), txt, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r"^(const\s+)?(uint16_t|uint8_t|float|int|int64_t)\s*", "", decl)
+            fields += [f.strip().lstrip("*").strip() for f in decl.split(",")]
+        got = [f[0] for f in getattr(_lib, name)._fields_]
+        assert got == fields, (name, got, fields)
+
+
+def test_no_gpu_means_loud_failure():
+    from signal_amd import _lib
+    from signal_amd.config import get_cfg_defaults
+    from signal_amd.modeling import make_frame
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "RGBNT201", "Signal.yml"))
+    model = make_frame(cfg, 171, 4, 0)
+    x = {m: torch.zeros(1, 3, 256, 128) for m in O.MODALITIES}
+    with pytest.raises(_lib.SignalHipError):
+        model(x, cam_label=torch.zeros(1, dtype=torch.long), training=False)
+
+
+def test_state_dict_contract():
+    """Parameter names/shapes are API: identical to the oracle's (= the reference's) keys;
+    91,166,209 trainable parameters as in the reference's training log."""
+    from signal_amd.config import get_cfg_defaults
+    from signal_amd.modeling import make_frame
+    for path, ocfg, want in (("RGBNT201", O.rgbnt201_config(), 91166209), ("RGBNT100", O.rgbnt100_config(), None)):
+        cfg = get_cfg_defaults()
+        cfg.merge_from_file(os.path.join(ROOT, "configs", path, "Signal.yml"))
+        model = make_frame(cfg, ocfg.num_classes, ocfg.camera_num, 0)
+        sd = O.init_state_dict(ocfg, seed=1)
+        own = {k: tuple(v.shape) for k, v in model.state_dict().items() if "num_batches_tracked" not in k}
+        assert own == {k: tuple(v.shape) for k, v in sd.items()}
+        if want:
+            assert sum(p.numel() for p in model.parameters() if p.requires_grad) == want
+        assert not model.bottleneck_var.bias.requires_grad
+        assert hasattr(model, "flops")
+
+
+def test_config_node():
+    from signal_amd.config import get_cfg_defaults
+    c = get_cfg_defaults()
+    c.merge_from_file(os.path.join(ROOT, "configs", "RGBNT100", "Signal.yml"))
+    c.merge_from_list(["MODEL.TOPK", "96", "SOLVER.BASE_LR", "0.001", "INPUT.SIZE_TRAIN", "[128,256]"])
+    assert (c.MODEL.TOPK, c.SOLVER.BASE_LR, c.INPUT.SIZE_TRAIN, c.MODEL.DIRECT) == (96, 0.001, [128, 256], 0)
+    with pytest.raises(KeyError):
+        c.merge_from_list(["MODEL.NOPE", "1"])
+    c.TEST.FEAT = 0          # train.py:40 injects this key before freeze
+    c.freeze()
+    with pytest.raises(AttributeError):
+        c.MODEL.TOPK = 1
+
+
+def test_reid_loss_matches_oracle_and_reference_fixture(golden):
+    from signal_amd.config import get_cfg_defaults
+    from signal_amd.layers.make_loss import make_loss, total_loss
+    g = golden("g6_reid")
+    gen = O._rng(int(g["seed"]))
+    score = O.randn(gen, 16, 171, std=2.0).requires_grad_(True)
+    feat = O.randn(gen, 16, 1536, std=1.0).requires_grad_(True)
+    target = torch.arange(16) // 4 + 7
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "RGBNT201", "Signal.yml"))
+    loss_fn, center = make_loss(cfg, 171)
+    loss = loss_fn(score=score, feat=feat, target=target, target_cam=None)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), 0.25 * float(g["id_loss"]) + float(g["tri_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(score.grad[:2].numpy(), g["dscore_rows"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(feat.grad.norm(dim=1).numpy(), g["dfeat_norm"], rtol=1e-4)
+    # loss assembly of processor.py:244-256 (sign 3, GAM + LAM)
+    out = (3, score, feat, score, feat, torch.tensor(2.0), torch.tensor(3.0))
+    tot = total_loss(cfg, out, loss_fn, target, None, "together_CLS_Patch")
+    np.testing.assert_allclose(tot.item(), 2 * loss.item() + 0.2 * 2.0 + 0.2 * 3.0, rtol=1e-6)
+    with pytest.raises(ValueError):
+        loss_fn(score=score, feat=feat, target=torch.zeros(16, dtype=torch.long), target_cam=None)
+
+
+def test_optimizer_rules_follow_the_reference():
+    from signal_amd.config import get_cfg_defaults
+    from signal_amd.solver.make_optimizer import gradless, param_hyper
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "RGBNT201", "Signal.yml"))
+    b = cfg.SOLVER.BASE_LR
+    assert param_hyper(cfg, "clip_vision_encoder.base.transformer.resblocks.0.mlp.c_fc.weight") == (5e-6, 1e-4)
+    assert param_hyper(cfg, "clip_vision_encoder.base.ln_pre.bias")[0] == 5e-6          # "base" overrides the bias factor
+    assert param_hyper(cfg, "clip_vision_encoder.cv_embed") == (b, 1e-4)
+    assert param_hyper(cfg, "SIM.modal_interactive.ffn.0.bias") == (2 * b, 1e-4)
+    assert param_hyper(cfg, "classifier.weight") == (b, 1e-4)
+    assert gradless("SIM.token_selection.W_v.weight") and not gradless("SIM.modal_interactive.norm1.weight")
+
+
+def test_bucket_plan_covers_the_flat_buffer():
+    from signal_amd.parallel.reducer import plan_buckets
+    ocfg = O.rgbnt201_config()
+    sd = O.init_state_dict(ocfg, seed=1)
+    names = [k for k in sd if "running_" not in k]
+    sizes = {n: sd[n].numel() for n in names}
+    pad = lambda n: (n + 63) // 64 * 64
+    offsets, off = {}, 0
+    for n in names:
+        offsets[n] = off
+        off += pad(sizes[n])
+    skip = lambda n: n.startswith("SIM.token_selection.")
+    blocks, rest = plan_buckets(names, offsets, sizes, off, skip=skip)
+    assert sorted(blocks) == list(range(12))
+    per_block = sum(pad(sizes[n]) for n in names if ".resblocks.0." in n)
+    assert all(hi - lo == per_block for lo, hi in blocks.values())
+    covered = sum(hi - lo for lo, hi in blocks.values()) + sum(hi - lo for lo, hi in rest)
+    skipped = sum(pad(sizes[n]) for n in names if skip(n))
+    assert covered + skipped == off
+    spans = sorted(list(blocks.values()) + rest)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "buckets must not overlap"
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from signal_amd.parallel.reducer import GradReducer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
+n = 4096
+g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+blocks = {0: (256, 1024), 1: (1024, 1792)}
+rest = [(0, 256), (2048, 4096)]            # [1792, 2048) plays the grad-less range: never reduced
+red = GradReducer(g, blocks, rest)
+p = torch.full((16,), float(rank))
+red.broadcast_params(p)
+assert torch.equal(p, torch.zeros(16))
+red.on_block_ready(1); red.on_block_ready(0)   # backward order
+red.finish()
+want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+mine = torch.arange(n, dtype=torch.float32) * (rank + 1)
+assert torch.equal(g[:1792], want[:1792]) and torch.equal(g[2048:], want[2048:])
+assert torch.equal(g[1792:2048], mine[1792:2048])
+assert not red.pending
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_grad_reducer_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    import socket
+    with socket.socket() as sk:            # a free port, so a stale rendezvous can never block the test
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, port], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=120)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append("TIMEOUT " + p.communicate()[0])
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs), outs
