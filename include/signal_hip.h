@@ -157,10 +157,12 @@ typedef struct SigBlockScratch {       /* reusable across blocks; pad rows must 
     uint16_t* dx_mid_b;                /* bf16 [Mp,D]  */
 } SigBlockScratch;
 int sig_block_fwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockActs* a, void* stream);
-/* dx_out (f32) and dx_out_b (its bf16 copy) are the gradient of x_out; writes dx_in and dx_in_b. */
+/* dx_out (f32) and dx_out_b (its bf16 copy) are the gradient of x_out; writes dx_in and dx_in_b (may alias dx_out*).
+ * dx_in_colsum (nullable, [D]) accumulates the column sums of dx_in: it IS the c_proj bias gradient of the block
+ * below.  b_proj_done != 0 says the stage above already did that for this block's own g->b_proj. */
 int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockActs* a, const SigBlockGrads* g,
                   const SigBlockScratch* s, const float* dx_out, const uint16_t* dx_out_b, float* dx_in,
-                  uint16_t* dx_in_b, void* stream);
+                  uint16_t* dx_in_b, float* dx_in_colsum, int b_proj_done, void* stream);
 
 /* --- ln_post + x @ proj on all tokens (clip/model.py:485-488) --- */
 typedef struct SigHeadParams {
@@ -178,6 +180,7 @@ int sig_head_fwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs*
 /* dtokens f32 [Mp,out_dim] (pad rows zero); scratch_dtok_b bf16 [Mp,out_dim]; scratch_dh bf16 [Mp,D] */
 int sig_head_bwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs* a, const SigHeadGrads* g,
                  const float* dtokens, uint16_t* scratch_dtok_b, uint16_t* scratch_dh, float* dx, uint16_t* dx_b,
+                 float* dx_colsum /* nullable [D]: += column sums of dx = last block's c_proj bias gradient */,
                  void* stream);
 
 /* ================================================================================================

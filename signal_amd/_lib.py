@@ -81,9 +81,9 @@ SIGNATURES.update({
     "sig_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sig_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sig_block_fwd": [_vp, _vp, _vp, _vp],
-    "sig_block_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sig_block_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sig_head_fwd": [_vp, _vp, _vp, _vp],
-    "sig_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sig_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sig_sim_select": [_vp, _i, _i, _vp, _vp, _vp],
     "sig_sim_fwd": [_vp, _i, _i, _vp, _vp, _vp],
     "sig_sim_bwd": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

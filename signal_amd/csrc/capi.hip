@@ -32,7 +32,7 @@ int sig_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, 
                 int ldo, const float* bias, const float* res, int ldr, void* aux, int ldaux, void* stream) {
     SigGemmNT p;
     p.A = A; p.Bt = Bt; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
-    p.out = out; p.ldo = ldo; p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0;
+    p.out = out; p.ldo = ldo; p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0; p.colsum = nullptr;
     return sig_launch_gemm_nt(p, epilogue, (hipStream_t)stream);
 }
 

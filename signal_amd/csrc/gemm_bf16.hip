@@ -101,6 +101,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     }
 
     // ---- epilogue: lane holds C[m][n..n+3], m = fr within the 16-row tile, n = 4g.. within the tile ----
+    f32x4_t csum[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) csum[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm + i * 16 + fr;
@@ -139,7 +142,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
                 uint2 o2 = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                 *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o2;
             }
+            csum[j] += v;
         }
+    }
+    // optional bias-gradient by-product: column sums of what was just written (this wave's 64 rows x 64 columns)
+    if (p.colsum) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = csum[j][e];
+                t += __shfl_xor(t, 1, 64);
+                t += __shfl_xor(t, 2, 64);
+                t += __shfl_xor(t, 4, 64);
+                t += __shfl_xor(t, 8, 64);
+                if (fr == 0) atomicAdd(p.colsum + n0 + wn + j * 16 + g * 4 + e, t);
+            }
     }
 }
 
@@ -359,7 +377,9 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
     }
     const int tiles = (p.I >> 7) * (p.J >> 7);
     const int ksteps = p.Mr >> 6;
-    int split = p.split > 0 ? p.split : sig_ceil_div(1024, tiles);  // ~4 workgroups per CU over the chip
+    // every split re-adds a whole 128x128 f32 tile with atomics (64 KB per workgroup, ~1.3 TB/s chip-wide), so use the
+    // FEWEST row chunks that still fill the chip once: tiles * split <= 512 resident workgroups (2 per CU)
+    int split = p.split > 0 ? p.split : (512 / tiles > 0 ? 512 / tiles : 1);
     if (split > ksteps) split = ksteps;
     const int per = sig_ceil_div(ksteps, split);
     split = sig_ceil_div(ksteps, per);

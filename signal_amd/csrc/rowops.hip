@@ -78,16 +78,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dxf, bf16_t* __restrict__ dxb,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
-    __shared__ float red[2][4][256 * LN_MAXV];
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D,
+                                                            float* __restrict__ dxsum) {
+    __shared__ float red[3][4][256 * LN_MAXV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 g[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV];
+    float4 g[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV], ax[LN_MAXV];
 #pragma unroll
     for (int it = 0; it < LN_MAXV; ++it) {
         const int c = lane * 4 + it * 256;
         g[it] = c < D ? *(const float4*)(gamma + c) : make_float4(0, 0, 0, 0);
         ag[it] = make_float4(0, 0, 0, 0);
         ab[it] = make_float4(0, 0, 0, 0);
+        ax[it] = make_float4(0, 0, 0, 0);
     }
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -130,26 +132,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                 }
                 if (dxf) *(float4*)(dxf + (size_t)row * D + c) = o;
                 if (dxb) *(uint2*)(dxb + (size_t)row * D + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+                ax[it].x += o.x; ax[it].y += o.y; ax[it].z += o.z; ax[it].w += o.w;
             }
         }
     }
-    if (!dgamma) return;
+    if (!dgamma && !dxsum) return;
 #pragma unroll
     for (int it = 0; it < LN_MAXV; ++it) {
         const int c = lane * 4 + it * 256;
         *(float4*)&red[0][wave][c] = ag[it];
         *(float4*)&red[1][wave][c] = ab[it];
+        *(float4*)&red[2][wave][c] = ax[it];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
-        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        if (dgamma) {
+            atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+        if (dxsum) atomicAdd(dxsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
 }
 
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                              const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma,
-                             float* dbeta, int M, int D, hipStream_t st) {
+                             float* dbeta, int M, int D, hipStream_t st, float* dx_colsum) {
     SIG_CHECK_ARG(M > 0 && D > 0 && (D & 3) == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D=%d unsupported", D);
     SIG_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SIG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
@@ -157,10 +164,10 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     if (blocks > 1024) blocks = 1024;
     if (dy_is_bf16)
         hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D);
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum);
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D);
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum);
     SIG_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }

@@ -29,6 +29,7 @@ struct SigGemmNT {
     void* aux;         // bf16 [M, ldaux]
     int ldaux;
     int band;          // column tiles per L2-resident weight band (filled by the launcher)
+    float* colsum;     // optional [N]: += column sums of the (f32, pre-rounding) output over the valid rows
 };
 int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st);
 int sig_prof_begin_impl(int epi, int N, int K, int max_launches);
@@ -51,7 +52,7 @@ int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* be
                              float* mean, float* rstd, int M, int D, float eps, hipStream_t st);
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                              const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma,
-                             float* dbeta, int M, int D, hipStream_t st);
+                             float* dbeta, int M, int D, hipStream_t st, float* dx_colsum = nullptr);
 int sig_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
 int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st);
 int sig_launch_colsum_bf16(const bf16_t* a, int lda, int M, int N, float* out, hipStream_t st);
@@ -79,7 +80,7 @@ int sig_launch_xattn_bwd(const float* q, const bf16_t* kv, const float* probs, c
                          bf16_t* dkv, hipStream_t st);
 
 int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
-                        int S, int L, int H, hipStream_t st);
+                        int S, int L, int H, hipStream_t st, float* dbias = nullptr);
 
 // ---- GAM / LAM (align.hip) ------------------------------------------------------------------------------
 int sig_launch_gam_fwd(const float* tokens, int B, int L, const float* temp, float* fh, float* nrm, float* lv, float* la,

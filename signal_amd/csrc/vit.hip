@@ -25,7 +25,11 @@ static SigGemmNT nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, 
                     const float* bias = nullptr, const float* res = nullptr, int ldr = 0, void* aux = nullptr, int ldaux = 0) {
     SigGemmNT p;
     p.A = A; p.lda = lda; p.Bt = Bt; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo;
-    p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0;
+    p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0; p.colsum = nullptr;
+    return p;
+}
+static SigGemmNT with_colsum(SigGemmNT p, float* colsum) {
+    p.colsum = colsum;
     return p;
 }
 static SigGemmTN tn(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int Mr, int I, int J, float* out, int ldo) {
@@ -95,7 +99,7 @@ int sig_block_fwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
 
 int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockActs* a, const SigBlockGrads* g,
                   const SigBlockScratch* s, const float* dx_out, const uint16_t* dx_out_b, float* dx_in, uint16_t* dx_in_b,
-                  void* stream) {
+                  float* dx_in_colsum, int b_proj_done, void* stream) {
     RUN(check_dims(d, "block_bwd"));
     SIG_CHECK_ARG(p && a && g && s && dx_out && dx_out_b && dx_in && dx_in_b, "block_bwd: null argument");
     SIG_CHECK_ARG(p->wt_in && p->wt_out && p->wt_fc && p->wt_proj, "block_bwd: transposed weights missing");
@@ -103,29 +107,31 @@ int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
     SIG_CHECK_ARG(s->du && s->dh && s->dqkv && s->dx_mid && s->dx_mid_b, "block_bwd: scratch missing");
     hipStream_t st = (hipStream_t)stream;
     const int M = d->S * d->L, Mp = pad128(M), D = d->D, F = d->F;
+    // Bias gradients are by-products of kernels that already hold the data: c_fc bias from the dGELU epilogue, out_proj
+    // bias from LN2's backward (column sums of dx_mid), and c_proj bias =
+    // column sums of dx_out, which the stage ABOVE accumulates when it writes dx_out (b_proj_done) -- else a pass here.
     // ---- MLP ----
-    // du = (dx_out W_proj) * QuickGELU'(u)
-    RUN(sig_launch_gemm_nt(nt(dx_out_b, D, p->wt_proj, D, M, F, D, s->du, F, nullptr, nullptr, 0, a->u, F), SIG_EPI_DGELU_BF16, st));
+    RUN(sig_launch_gemm_nt(with_colsum(nt(dx_out_b, D, p->wt_proj, D, M, F, D, s->du, F, nullptr, nullptr, 0, a->u, F), g->b_fc),
+                           SIG_EPI_DGELU_BF16, st));                                              // du = (dx_out W_proj) * QuickGELU'(u)
     RUN(sig_launch_gemm_tn(tn(dx_out_b, D, a->g, F, Mp, D, F, g->w_proj, F), st));
-    RUN(sig_launch_colsum_bf16(dx_out_b, D, M, D, g->b_proj, st));
-    // dh2 = du W_fc
-    RUN(sig_launch_gemm_nt(nt(s->du, F, p->wt_fc, F, M, D, F, s->dh, D), SIG_EPI_BF16, st));
+    if (!b_proj_done) RUN(sig_launch_colsum_bf16(dx_out_b, D, M, D, g->b_proj, st));
+    RUN(sig_launch_gemm_nt(nt(s->du, F, p->wt_fc, F, M, D, F, s->dh, D), SIG_EPI_BF16, st));     // dh2 = du W_fc
     RUN(sig_launch_gemm_tn(tn(s->du, F, a->h2, D, Mp, F, D, g->w_fc, D), st));
-    RUN(sig_launch_colsum_bf16(s->du, F, M, F, g->b_fc, st));
     // dx_mid = dx_out + LN2'(dh2)
     RUN(sig_launch_layernorm_bwd(s->dh, 1, a->x_mid, p->ln2_w, a->mean2, a->rstd2, dx_out, s->dx_mid, s->dx_mid_b, g->ln2_w,
-                                 g->ln2_b, M, D, st));
+                                 g->ln2_b, M, D, st, g->b_out));
     // ---- attention ----
     RUN(sig_launch_gemm_nt(nt(s->dx_mid_b, D, p->wt_out, D, M, D, D, s->dh, D), SIG_EPI_BF16, st));  // d attn
     RUN(sig_launch_gemm_tn(tn(s->dx_mid_b, D, a->attn, D, Mp, D, D, g->w_out, D), st));
-    RUN(sig_launch_colsum_bf16(s->dx_mid_b, D, M, D, g->b_out, st));
-    RUN(sig_launch_attn_bwd(a->qkv, a->attn, s->dh, a->lse, s->dqkv, d->S, d->L, d->H, st));
+    // (in_proj bias: every (sequence) workgroup of a head would hit the same 192 addresses -- measured 2x slower with
+    //  in-kernel atomics -- so it stays a separate 25 us column-sum pass over dqkv)
+    RUN(sig_launch_attn_bwd(a->qkv, a->attn, s->dh, a->lse, s->dqkv, d->S, d->L, d->H, st, nullptr));
+    RUN(sig_launch_colsum_bf16(s->dqkv, 3 * D, M, 3 * D, g->b_in, st));
     RUN(sig_launch_gemm_nt(nt(s->dqkv, 3 * D, p->wt_in, 3 * D, M, D, 3 * D, s->dh, D), SIG_EPI_BF16, st));  // dh1
     RUN(sig_launch_gemm_tn(tn(s->dqkv, 3 * D, a->h1, D, Mp, 3 * D, D, g->w_in, D), st));
-    RUN(sig_launch_colsum_bf16(s->dqkv, 3 * D, M, 3 * D, g->b_in, st));
     // dx_in = dx_mid + LN1'(dh1)
     RUN(sig_launch_layernorm_bwd(s->dh, 1, a->x_in, p->ln1_w, a->mean1, a->rstd1, s->dx_mid, dx_in, dx_in_b, g->ln1_w, g->ln1_b,
-                                 M, D, st));
+                                 M, D, st, dx_in_colsum));
     return 0;
 }
 
@@ -143,7 +149,8 @@ int sig_head_fwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs*
 }
 
 int sig_head_bwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs* a, const SigHeadGrads* g,
-                 const float* dtokens, uint16_t* scratch_dtok_b, uint16_t* scratch_dh, float* dx, uint16_t* dx_b, void* stream) {
+                 const float* dtokens, uint16_t* scratch_dtok_b, uint16_t* scratch_dh, float* dx, uint16_t* dx_b,
+                 float* dx_colsum, void* stream) {
     RUN(check_dims(d, "head_bwd"));
     SIG_CHECK_ARG(p && a && g && dtokens && scratch_dtok_b && scratch_dh && dx && dx_b && p->proj, "head_bwd: null argument");
     SIG_CHECK_ARG(a->mean && a->rstd, "head_bwd: forward ran without saving statistics");
@@ -152,7 +159,7 @@ int sig_head_bwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs*
     RUN(sig_launch_cast_bf16(dtokens, scratch_dtok_b, (size_t)Mp * O, st));
     RUN(sig_launch_gemm_nt(nt(scratch_dtok_b, O, p->proj, O, M, D, O, scratch_dh, D), SIG_EPI_BF16, st));  // d ln_post out
     RUN(sig_launch_gemm_tn(tn(a->hp, D, scratch_dtok_b, O, Mp, D, O, g->proj, O), st));                    // d proj [D,O]
-    RUN(sig_launch_layernorm_bwd(scratch_dh, 1, a->x, p->ln_w, a->mean, a->rstd, nullptr, dx, dx_b, g->ln_w, g->ln_b, M, D, st));
+    RUN(sig_launch_layernorm_bwd(scratch_dh, 1, a->x, p->ln_w, a->mean, a->rstd, nullptr, dx, dx_b, g->ln_w, g->ln_b, M, D, st, dx_colsum));
     return 0;
 }
 

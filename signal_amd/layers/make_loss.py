@@ -32,7 +32,9 @@ def euclidean_dist(x, y):
 def hard_example_mining(dist_mat, labels):
     """hardest positive (max over same id, self included) and hardest negative (min over other ids) per anchor"""
     same = labels.view(-1, 1) == labels.view(1, -1)
-    if bool(same.all()):
+    if same.is_cuda:      # no host sync on the hot path: device-side assertion
+        torch._assert_async(~same.all(), "batch-hard mining needs at least two identities in the batch")
+    elif bool(same.all()):
         raise ValueError("batch-hard mining needs at least two identities in the batch (triplet_loss.py:79-84)")
     d_ap = torch.where(same, dist_mat, dist_mat.new_full((), float("-inf"))).max(1).values
     d_an = torch.where(same, dist_mat.new_full((), float("inf")), dist_mat).min(1).values

@@ -210,6 +210,8 @@ class HipPath:
                 kw[k] = self._pk(n) if k.startswith("w_") else self._p(n)
             for k, (r, c) in shapes.items():
                 kw["wt_" + k[2:]] = T(names[k], r, c)
+            self.b_proj_grad = getattr(self, "b_proj_grad", []) if i else []
+            self.b_proj_grad.append(self._g(names["b_proj"]))
             self.block_p.append(fill(_lib.SigBlockParams, **kw))
             self.block_g.append(fill(_lib.SigBlockGrads, **{k: self._g(n) for k, n in names.items()}))
         self.proj_t = T(base + "proj", D, O)      # forward operand proj^T [O, D]
@@ -346,11 +348,13 @@ class HipPath:
         M, st, d = ws["M"], _stream(), ref(ws["dims"])
         ws["dtokens"][:M].copy_(dtokens.reshape(M, self.out_dim))
         _lib.call("sig_head_bwd", d, ref(self.head_p), ref(ws["head_a"]), ref(self.head_g), ws["dtokens"].data_ptr(),
-                  ws["dtok_b"].data_ptr(), ws["dh"].data_ptr(), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(), st)
+                  ws["dtok_b"].data_ptr(), ws["dh"].data_ptr(), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(),
+                  self.b_proj_grad[self.layers - 1].data_ptr(), st)
         for i in reversed(range(self.layers)):
+            below = self.b_proj_grad[i - 1].data_ptr() if i > 0 else None   # column sums of dx_in = block i-1's c_proj bias grad
             _lib.call("sig_block_bwd", d, ref(self.block_p[i]), ref(ws["block_a"][i]), ref(self.block_g[i]),
                       ref(ws["scratch"]), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(), ws["dx"].data_ptr(),
-                      ws["dx_b"].data_ptr(), st)
+                      ws["dx_b"].data_ptr(), below, 1, st)
             if self.on_block_grads_ready is not None:
                 self.on_block_grads_ready(i)
         cam = ws["cam"]
