@@ -153,8 +153,7 @@ __device__ __forceinline__ int d_off(int row, int chunk) {
 #define ATB_ROWS 144  // 9 tiles; reads past it are clamped (they only ever meet zero probabilities)
 __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                       bf16_t* __restrict__ dqkv, int S, int L, int H,
-                                                       float* __restrict__ dbias) {
+                                                       bf16_t* __restrict__ dqkv, int S, int L, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem;
     char* sK = smem + ATB_ROWS * 128;
@@ -206,11 +205,6 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
     const int NT = (L + 15) >> 4;
     const int tq = fr >> 2, tp = fr & 3;
     const float scale = 0.125f;
-
-    // optional by-product: column sums of dQ / dK / dV over this head's tokens = in_proj_bias gradient
-    f32x4_t cq[4], ck[4], cv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) cq[dt] = ck[dt] = cv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // ------------------------------ pass A: dQ (wave owns query tiles) ------------------------------
     for (int qt = wave; qt < NT; qt += 3) {
@@ -269,10 +263,8 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
         if (q < L) {
             bf16_t* orow = dqkv + ((size_t)s * L + q) * D3 + h * 64 + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4; ++dt)
                 *(uint2*)(orow + dt * 16) = make_uint2(pack2bf(o[dt][0], o[dt][1]), pack2bf(o[dt][2], o[dt][3]));
-                cq[dt] += o[dt];
-            }
         }
     }
 
@@ -341,35 +333,13 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
             for (int dt = 0; dt < 4; ++dt) {
                 *(uint2*)(krow + dt * 16) = make_uint2(pack2bf(dk[dt][0], dk[dt][1]), pack2bf(dk[dt][2], dk[dt][3]));
                 *(uint2*)(vrow + dt * 16) = make_uint2(pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3]));
-                ck[dt] += dk[dt];
-                cv[dt] += dv[dt];
             }
         }
-    }
-    if (dbias) {   // reduce over the 16 token lanes (fr), then one atomic per column per wave
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = cq[dt][e], b = ck[dt][e], c = cv[dt][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    b += __shfl_xor(b, o, 64);
-                    c += __shfl_xor(c, o, 64);
-                }
-                if (fr == 0) {
-                    const int col = h * 64 + dt * 16 + 4 * g + e;
-                    atomicAdd(dbias + col, a);
-                    atomicAdd(dbias + Dm + col, b);
-                    atomicAdd(dbias + 2 * Dm + col, c);
-                }
-            }
     }
 }
 
 int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
-                        int S, int L, int H, hipStream_t st, float* dbias) {
+                        int S, int L, int H, hipStream_t st) {
     SIG_CHECK_ARG(qkv && out && dout && lse && dqkv, "attn_bwd: null pointer");
     SIG_CHECK_ARG(S > 0 && H > 0 && L > 0 && L <= ATT_KROWS, "attn_bwd: L=%d must be in 1..%d", L, ATT_KROWS);
     const int lds = 4 * ATB_ROWS * 128 + 2 * ATB_ROWS * 4;
@@ -378,7 +348,7 @@ int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H, dbias);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
     SIG_CHECK_LAUNCH("attn_bwd");
     return 0;
 }

@@ -80,7 +80,7 @@ int sig_launch_xattn_bwd(const float* q, const bf16_t* kv, const float* probs, c
                          bf16_t* dkv, hipStream_t st);
 
 int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
-                        int S, int L, int H, hipStream_t st, float* dbias = nullptr);
+                        int S, int L, int H, hipStream_t st);
 
 // ---- GAM / LAM (align.hip) ------------------------------------------------------------------------------
 int sig_launch_gam_fwd(const float* tokens, int B, int L, const float* temp, float* fh, float* nrm, float* lv, float* la,

@@ -125,7 +125,7 @@ int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
     RUN(sig_launch_gemm_tn(tn(s->dx_mid_b, D, a->attn, D, Mp, D, D, g->w_out, D), st));
     // (in_proj bias: every (sequence) workgroup of a head would hit the same 192 addresses -- measured 2x slower with
     //  in-kernel atomics -- so it stays a separate 25 us column-sum pass over dqkv)
-    RUN(sig_launch_attn_bwd(a->qkv, a->attn, s->dh, a->lse, s->dqkv, d->S, d->L, d->H, st, nullptr));
+    RUN(sig_launch_attn_bwd(a->qkv, a->attn, s->dh, a->lse, s->dqkv, d->S, d->L, d->H, st));
     RUN(sig_launch_colsum_bf16(s->dqkv, 3 * D, M, 3 * D, g->b_in, st));
     RUN(sig_launch_gemm_nt(nt(s->dqkv, 3 * D, p->wt_in, 3 * D, M, D, 3 * D, s->dh, D), SIG_EPI_BF16, st));  // dh1
     RUN(sig_launch_gemm_tn(tn(s->dqkv, 3 * D, a->h1, D, Mp, 3 * D, D, g->w_in, D), st));
