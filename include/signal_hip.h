@@ -287,6 +287,29 @@ int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16
                   const float* seg_lr, const float* seg_wd, int nseg, float beta1, float beta2, float eps, int step,
                   float grad_scale, size_t n, void* stream);
 
+/* ================================================================================================
+ * ReID head.  All f32, B <= 128.
+ * sig_bnneck_fwd: y = BatchNorm1d(x) in TRAINING mode (batch statistics, running stats updated with `momentum`;
+ *   pass NULL running stats to skip) and logits = y W^T with the bias-free classifier W [C,F]
+ *   (modeling/make_model.py:77-81,194-195,213-219).  sig_bnneck_bwd: dW += dlogits^T y, dx += BN'(dlogits W)
+ *   (dx is ACCUMULATED: the triplet gradient of the same features is usually already in it), dbn_w += ...,
+ *   dbn_b (may be NULL: the reference freezes it).
+ * sig_reid_loss: loss = id_weight * CE_labelsmooth(logits, target; eps) + triplet_weight * batch-hard triplet(feat)
+ *   (layers/softmax_loss.py:23-34, layers/triplet_loss.py:16-135, layers/make_loss.py:109-150); margin < 0 selects the
+ *   soft-margin form (MODEL.NO_MARGIN).  With dlogits / dfeat non-NULL it also writes dL/dlogits and ACCUMULATES
+ *   dL/dfeat, both times upstream[0] (device scalar, NULL = 1).  gram [B,B], pidx/nidx [B], coef [2B] are scratch.
+ * ================================================================================================ */
+int sig_bnneck_fwd(const float* x, const float* bn_w, const float* bn_b, float* running_mean, float* running_var,
+                   float momentum, const float* cls_w, int B, int F, int C, float* y, float* mean, float* rstd,
+                   float* logits, void* stream);
+int sig_bnneck_bwd(const float* x, const float* y, const float* bn_w, const float* mean, const float* rstd,
+                   const float* cls_w, const float* dlogits, int B, int F, int C, float* dy_scratch, float* dx,
+                   float* dbn_w, float* dbn_b, float* dcls_w, void* stream);
+int sig_reid_loss(const float* logits, const float* feat, const int64_t* target, int B, int F, int C,
+                  float label_smooth_eps, float id_weight, float triplet_weight, float margin, const float* upstream,
+                  float* loss, float* dlogits, float* gram, int* pidx, int* nidx, float* coef, float* dfeat,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

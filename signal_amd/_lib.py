@@ -72,6 +72,9 @@ SigLamActs = _struct("SigLamActs", ["xb", "q", "a1", "a1pre", "a2pre", "offs", "
 SigLamScratch = _struct("SigLamScratch", ["da1pre", "dq", "dx"])
 
 SIGNATURES.update({
+    "sig_bnneck_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sig_bnneck_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sig_reid_loss": [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sig_adam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _f, _sz, _vp],
     "sig_gam_fwd": [_vp, _i, _i, _vp, _vp, _vp],
     "sig_gam_bwd": [_i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -102,4 +102,22 @@ int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16
                            (hipStream_t)stream);
 }
 
+int sig_bnneck_fwd(const float* x, const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum,
+                   const float* cls_w, int B, int F, int C, float* y, float* mean, float* rstd, float* logits, void* stream) {
+    return sig_launch_bnneck_fwd(x, bn_w, bn_b, running_mean, running_var, momentum, cls_w, B, F, C, y, mean, rstd, logits,
+                                 (hipStream_t)stream);
+}
+int sig_bnneck_bwd(const float* x, const float* y, const float* bn_w, const float* mean, const float* rstd, const float* cls_w,
+                   const float* dlogits, int B, int F, int C, float* dy_scratch, float* dx, float* dbn_w, float* dbn_b, float* dcls_w,
+                   void* stream) {
+    return sig_launch_bnneck_bwd(x, y, bn_w, mean, rstd, cls_w, dlogits, B, F, C, dy_scratch, dx, dbn_w, dbn_b, dcls_w,
+                                 (hipStream_t)stream);
+}
+int sig_reid_loss(const float* logits, const float* feat, const int64_t* target, int B, int F, int C, float label_smooth_eps,
+                  float id_weight, float triplet_weight, float margin, const float* upstream, float* loss, float* dlogits,
+                  float* gram, int* pidx, int* nidx, float* coef, float* dfeat, void* stream) {
+    return sig_launch_reid_loss(logits, feat, target, B, F, C, label_smooth_eps, id_weight, triplet_weight, margin, upstream, loss,
+                                dlogits, gram, pidx, nidx, coef, dfeat, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -100,3 +100,13 @@ int sig_launch_lam_tail_bwd(const float* tokens, int m, int B, int L, int h, int
 // ---- optimizer (optim.hip) ------------------------------------------------------------------------------
 int sig_launch_adam(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, const int* seg_end, const float* seg_lr,
                     const float* seg_wd, int nseg, float b1, float b2, float eps, int step, float gscale, size_t n, hipStream_t st);
+
+// ---- ReID head (reid.hip) ----------------------------------------------------------------------------------
+int sig_launch_bnneck_fwd(const float* x, const float* bn_w, const float* bn_b, float* run_mean, float* run_var, float momentum,
+                          const float* cls_w, int B, int F, int C, float* y, float* mean, float* rstd, float* logits, hipStream_t st);
+int sig_launch_bnneck_bwd(const float* x, const float* y, const float* bn_w, const float* mean, const float* rstd, const float* cls_w,
+                          const float* dlogits, int B, int F, int C, float* dy_scratch, float* dx, float* dbn_w, float* dbn_b, float* dcls_w,
+                          hipStream_t st);
+int sig_launch_reid_loss(const float* logits, const float* feat, const int64_t* target, int B, int F, int C, float eps, float w_id,
+                         float w_tri, float margin, const float* upstream, float* loss, float* dlogits, float* gram, int* pidx, int* nidx,
+                         float* coef, float* dfeat, hipStream_t st);

@@ -1,7 +1,8 @@
 """ReID loss of the train step (layers/make_loss.py:29-193, softmax_loss.py:4-34, triplet_loss.py:16-135 of the
 reference): ID_LOSS_WEIGHT * label-smoothed CE + TRIPLET_LOSS_WEIGHT * batch-hard triplet (soft-margin when
 MODEL.NO_MARGIN, the default).  Same factory signature: make_loss(cfg, num_classes) -> (loss_func, center_criterion).
-These run as PyTorch device ops in this round (fused ReID loss is the next kernel)."""
+On device tensors the loss runs in HIP (signal_amd/csrc/reid.hip via modeling/reid_head.py); the PyTorch code
+below is the host-tensor / list-of-heads form and what the CPU tests compare against the reference fixture."""
 from __future__ import annotations
 
 import torch
@@ -82,7 +83,15 @@ def make_loss(cfg, num_classes):
         def loss_func(score, feat, target, target_cam):
             return F.cross_entropy(score.float(), target)
     elif sampler == "softmax_triplet":
+        eps = 0.1 if smooth else 0.0
+        margin = None if cfg.MODEL.NO_MARGIN else cfg.SOLVER.MARGIN
+
         def loss_func(score, feat, target, target_cam):
+            if torch.is_tensor(score) and torch.is_tensor(feat) and score.is_cuda:
+                # device tensors: one fused HIP path (sig_reid_loss) -- CE + gram + batch-hard mining + both gradients
+                from ..modeling.reid_head import reid_loss
+                return reid_loss(score, feat, target, eps, cfg.MODEL.ID_LOSS_WEIGHT, cfg.MODEL.TRIPLET_LOSS_WEIGHT, margin)
+            # host tensors / the list-of-heads form of the reference: plain PyTorch
             return cfg.MODEL.ID_LOSS_WEIGHT * _id(score, target) + cfg.MODEL.TRIPLET_LOSS_WEIGHT * _tri(feat, target)
     else:
         raise ValueError(f"expected sampler should be softmax or softmax_triplet but got {sampler}")

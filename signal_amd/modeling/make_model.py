@@ -7,7 +7,7 @@
 Same parameter names, same training tuples (`sign`, score/feature pairs, loss_area, patch_loss), same
 inference features.  The three backbone calls of the reference (make_model.py:181-183) are batched into one
 [3B,129,768] problem that runs in hand-written HIP (signal_amd/csrc); SIM, GAM and LAM run in HIP as well.
-BNNeck + classifier (make_model.py:194-219) stay on PyTorch device ops in this round."""
+BNNeck + classifier (make_model.py:194-219) run in HIP too (csrc/reid.hip)."""
 from __future__ import annotations
 
 import torch
@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from . import params as P
 from .hip_engine import BackboneFn, HipPath, SimFn
+from .reid_head import bnneck_classifier
 
 
 class Signal(nn.Module):
@@ -154,15 +155,15 @@ class Signal(nn.Module):
             return ori if not self.use_A else torch.cat([ori, vars_total], dim=-1)
 
         if self.use_A:
-            vars_score = self.classifier_var(self.bottleneck_var(vars_total))
+            vars_score = bnneck_classifier(self.bottleneck_var, self.classifier_var, vars_total)
         if self.direct:
             ori = torch.cat([RGB_global, NI_global, TI_global], dim=-1)
-            ori_score = self.classifier(self.bottleneck(ori))
+            ori_score = bnneck_classifier(self.bottleneck, self.classifier, ori)
             head = (ori_score, ori)
         else:
-            head = (self.classifier_r(self.bottleneck_r(RGB_global)), RGB_global,
-                    self.classifier_n(self.bottleneck_n(NI_global)), NI_global,
-                    self.classifier_t(self.bottleneck_t(TI_global)), TI_global)
+            head = (bnneck_classifier(self.bottleneck_r, self.classifier_r, RGB_global), RGB_global,
+                    bnneck_classifier(self.bottleneck_n, self.classifier_n, NI_global), NI_global,
+                    bnneck_classifier(self.bottleneck_t, self.classifier_t, TI_global), TI_global)
         if not self.use_A:
             return (1, *head)
         if not self.use_B:

@@ -1,0 +1,98 @@
+"""HIP ReID head: BNNeck + classifier (make_model.py:194-219) and the ID + triplet loss (layers/make_loss.py)
+as autograd Functions over the C ABI (sig_bnneck_*, sig_reid_loss).  fp32; device tensors only."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class BnneckClassifierFn(torch.autograd.Function):
+    """score = classifier(bottleneck(feat)), BatchNorm1d in training mode (batch statistics)."""
+
+    @staticmethod
+    def forward(ctx, feat, bn_w, bn_b, cls_w, run_mean, run_var, momentum):
+        x = feat.contiguous().float()
+        B, F = x.shape
+        C = cls_w.shape[0]
+        dev = x.device
+        y = torch.empty(B, F, device=dev)
+        mean, rstd = torch.empty(F, device=dev), torch.empty(F, device=dev)
+        logits = torch.empty(B, C, device=dev)
+        _lib.call("sig_bnneck_fwd", x.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(), _p(run_mean), _p(run_var), float(momentum),
+                  cls_w.data_ptr(), B, F, C, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), logits.data_ptr(), _st())
+        ctx.save_for_backward(x, y, bn_w, mean, rstd, cls_w)
+        ctx.need_b = bn_b.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, y, bn_w, mean, rstd, cls_w = ctx.saved_tensors
+        B, F = x.shape
+        C = cls_w.shape[0]
+        dev = x.device
+        dl = dlogits.contiguous().float()
+        dx, dy = torch.zeros(B, F, device=dev), torch.empty(B, F, device=dev)
+        dw, dcls = torch.zeros(F, device=dev), torch.zeros(C, F, device=dev)
+        db = torch.zeros(F, device=dev) if ctx.need_b else None
+        _lib.call("sig_bnneck_bwd", x.data_ptr(), y.data_ptr(), bn_w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), cls_w.data_ptr(),
+                  dl.data_ptr(), B, F, C, dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), _p(db), dcls.data_ptr(), _st())
+        return dx, dw, db, dcls, None, None, None
+
+
+def bnneck_classifier(bn: torch.nn.BatchNorm1d, cls: torch.nn.Linear, feat: torch.Tensor) -> torch.Tensor:
+    if not feat.is_cuda:
+        raise _lib.SignalHipError("signal_amd's ReID head runs on the GPU only")
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return BnneckClassifierFn.apply(feat, bn.weight, bn.bias, cls.weight, bn.running_mean, bn.running_var,
+                                    0.1 if bn.momentum is None else bn.momentum)
+
+
+class ReidLossFn(torch.autograd.Function):
+    """id_weight * CE_labelsmooth(score) + triplet_weight * batch-hard triplet(feat)."""
+
+    @staticmethod
+    def forward(ctx, score, feat, target, eps, w_id, w_tri, margin):
+        s, f = score.contiguous().float(), feat.contiguous().float()
+        t = target.contiguous().to(torch.int64)
+        B, C = s.shape
+        F = f.shape[1]
+        dev = s.device
+        loss = torch.zeros(1, device=dev)
+        gram, coef = torch.empty(B, B, device=dev), torch.empty(2 * B, device=dev)
+        pidx, nidx = torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.call("sig_reid_loss", s.data_ptr(), f.data_ptr(), t.data_ptr(), B, F, C, float(eps), float(w_id), float(w_tri), float(margin),
+                  None, loss.data_ptr(), None, gram.data_ptr(), pidx.data_ptr(), nidx.data_ptr(), coef.data_ptr(), None, _st())
+        ctx.save_for_backward(s, f, t)
+        ctx.hp = (float(eps), float(w_id), float(w_tri), float(margin))
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        s, f, t = ctx.saved_tensors
+        eps, w_id, w_tri, margin = ctx.hp
+        B, C = s.shape
+        F = f.shape[1]
+        dev = s.device
+        up = gout.contiguous().float().reshape(1)
+        dlogits, dfeat = torch.empty(B, C, device=dev), torch.zeros(B, F, device=dev)
+        scratch = torch.zeros(1, device=dev)
+        gram, coef = torch.empty(B, B, device=dev), torch.empty(2 * B, device=dev)
+        pidx, nidx = torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.call("sig_reid_loss", s.data_ptr(), f.data_ptr(), t.data_ptr(), B, F, C, eps, w_id, w_tri, margin, up.data_ptr(),
+                  scratch.data_ptr(), dlogits.data_ptr(), gram.data_ptr(), pidx.data_ptr(), nidx.data_ptr(), coef.data_ptr(),
+                  dfeat.data_ptr(), _st())
+        return dlogits, dfeat, None, None, None, None, None
+
+
+def reid_loss(score, feat, target, eps, w_id, w_tri, margin):
+    return ReidLossFn.apply(score, feat, target, eps, w_id, w_tri, -1.0 if margin is None else float(margin))

@@ -202,3 +202,57 @@ def test_fused_adam_matches_torch(dev):
     # the bf16 operand mirror follows the update
     n = "clip_vision_encoder.base.transformer.resblocks.3.mlp.c_fc.weight"
     assert torch.equal(hip._pk(n), hip.flat.byname[n].data.to(torch.bfloat16))
+
+
+def test_reid_loss_hip_vs_reference_fixture(dev, golden):
+    """sig_reid_loss (label-smoothed CE + batch-hard soft-margin triplet, fwd + bwd) against fixture G6."""
+    from signal_amd.modeling.reid_head import reid_loss
+    g = golden("g6_reid")
+    gen = O._rng(int(g["seed"]))
+    score = O.randn(gen, 16, 171, std=2.0).to(dev).requires_grad_(True)
+    feat = O.randn(gen, 16, 1536, std=1.0).to(dev).requires_grad_(True)
+    target = (torch.arange(16) // 4 + 7).to(dev)
+    loss = reid_loss(score, feat, target, 0.1, 0.25, 1.0, None)
+    (2.0 * loss).backward()                      # upstream gradient 2: exercises the device-scalar scaling
+    np.testing.assert_allclose(loss.item(), 0.25 * float(g["id_loss"]) + float(g["tri_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(score.grad[:2].cpu().numpy() / 2, g["dscore_rows"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(feat.grad.norm(dim=1).cpu().numpy() / 2, g["dfeat_norm"], rtol=1e-4)
+    # margin form against the PyTorch host implementation
+    from signal_amd.layers.make_loss import TripletLoss
+    f2 = feat.detach().clone().requires_grad_(True)
+    l2 = reid_loss(score.detach(), f2, target, 0.0, 0.0, 1.0, 0.3)
+    l2.backward()
+    f3 = feat.detach().cpu().clone().requires_grad_(True)
+    l3 = TripletLoss(0.3)(f3, target.cpu())[0]
+    l3.backward()
+    np.testing.assert_allclose(l2.item(), l3.item(), rtol=1e-5)
+    assert rel_err(f2.grad, f3.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,F,C", [(8, 1536, 171), (64, 512, 50)])
+def test_bnneck_classifier_hip_vs_torch(dev, B, F, C):
+    from signal_amd.modeling.reid_head import bnneck_classifier
+    gen = torch.Generator().manual_seed(B + F)
+    x = (torch.randn(B, F, generator=gen) * 2 + 0.3)
+    bn_h, bn_t = torch.nn.BatchNorm1d(F), torch.nn.BatchNorm1d(F)
+    cl_h, cl_t = torch.nn.Linear(F, C, bias=False), torch.nn.Linear(F, C, bias=False)
+    with torch.no_grad():
+        bn_h.weight.copy_(1 + 0.1 * torch.randn(F, generator=gen)); bn_t.weight.copy_(bn_h.weight)
+        cl_t.weight.copy_(cl_h.weight)
+    for bn in (bn_h, bn_t):
+        bn.bias.requires_grad_(False)
+    bn_h.to(dev); cl_h.to(dev)
+    xh = x.to(dev).requires_grad_(True)
+    xt = x.clone().requires_grad_(True)
+    w = torch.randn(B, C, generator=gen)
+    sh = bnneck_classifier(bn_h, cl_h, xh)
+    (sh * w.to(dev)).sum().backward()
+    st = cl_t(bn_t(xt))
+    (st * w).sum().backward()
+    assert rel_err(sh, st) < 1e-5
+    assert rel_err(xh.grad, xt.grad) < 1e-4
+    assert rel_err(bn_h.weight.grad, bn_t.weight.grad) < 1e-4
+    assert rel_err(cl_h.weight.grad, cl_t.weight.grad) < 1e-5
+    assert bn_h.bias.grad is None
+    assert rel_err(bn_h.running_mean, bn_t.running_mean) < 1e-5 and rel_err(bn_h.running_var, bn_t.running_var) < 1e-5
+    assert int(bn_h.num_batches_tracked) == 1
