@@ -79,6 +79,9 @@ int sig_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout,
 /* Packing helpers: f32 -> bf16 (optionally transposed), column sums (bias gradients, accumulated). */
 int sig_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, void* stream);
+/* n transposes in one launch: table[d] = {src f32*, dst bf16*, rows, cols} as int64, tile_start[d] = index of matrix d's
+ * first 64x64 tile in the flattened grid, tile_start[n] = total_tiles. */
+int sig_transpose_cast_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, void* stream);
 int sig_colsum_bf16(const uint16_t* a, int lda, int M, int N, float* out, void* stream);
 int sig_colsum_f32(const float* a, int lda, int M, int N, float* out, void* stream);
 

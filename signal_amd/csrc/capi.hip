@@ -71,6 +71,9 @@ int sig_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
 int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, void* stream) {
     return sig_launch_transpose_cast_bf16(src, dst, rows, cols, (hipStream_t)stream);
 }
+int sig_transpose_cast_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, void* stream) {
+    return sig_launch_transpose_cast_multi((const long long*)table, tile_start, n, total_tiles, (hipStream_t)stream);
+}
 int sig_colsum_bf16(const uint16_t* a, int lda, int M, int N, float* out, void* stream) {
     return sig_launch_colsum_bf16(a, lda, M, N, out, (hipStream_t)stream);
 }

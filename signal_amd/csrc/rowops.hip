@@ -73,31 +73,32 @@ int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* be
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (register partials per wave, LDS across the 4 waves,
 // one atomic per column per workgroup).
 // ------------------------------------------------------------------------------------------------
-template <bool DY_BF16>
+template <bool DY_BF16, int NV, bool SUMX>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dxf, bf16_t* __restrict__ dxb,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D,
                                                             float* __restrict__ dxsum) {
-    __shared__ float red[3][4][256 * LN_MAXV];
+    // NV = float4 per lane (D <= 256*NV): sized to the row so the per-lane accumulators stay small (more waves per SIMD)
+    __shared__ float red[SUMX ? 3 : 2][4][256 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 g[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV], ax[LN_MAXV];
+    float4 ag[NV], ab[NV], ax[SUMX ? NV : 1];
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; ++it) {
-        const int c = lane * 4 + it * 256;
-        g[it] = c < D ? *(const float4*)(gamma + c) : make_float4(0, 0, 0, 0);
+    for (int it = 0; it < NV; ++it) {
         ag[it] = make_float4(0, 0, 0, 0);
         ab[it] = make_float4(0, 0, 0, 0);
-        ax[it] = make_float4(0, 0, 0, 0);
+        if (SUMX) ax[it] = make_float4(0, 0, 0, 0);
     }
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float4 dyv[LN_MAXV], xh[LN_MAXV];
+        float4 dyv[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int it = 0; it < LN_MAXV; ++it) {
+        for (int it = 0; it < NV; ++it) {
             const int c = lane * 4 + it * 256;
+            dyv[it] = make_float4(0, 0, 0, 0);
+            xh[it] = make_float4(0, 0, 0, 0);
             if (c < D) {
                 if (DY_BF16) {
                     const uint2 u = *(const uint2*)((const bf16_t*)dy_ + (size_t)row * D + c);
@@ -107,8 +108,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                     dyv[it] = *(const float4*)((const float*)dy_ + (size_t)row * D + c);
                 }
                 const float4 xv = *(const float4*)(x + (size_t)row * D + c);
+                const float4 g = *(const float4*)(gamma + c);
                 xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                const float a0 = dyv[it].x * g[it].x, a1 = dyv[it].y * g[it].y, a2 = dyv[it].z * g[it].z, a3 = dyv[it].w * g[it].w;
+                const float a0 = dyv[it].x * g.x, a1 = dyv[it].y * g.y, a2 = dyv[it].z * g.z, a3 = dyv[it].w * g.w;
                 s1 += a0 + a1 + a2 + a3;
                 s2 += a0 * xh[it].x + a1 * xh[it].y + a2 * xh[it].z + a3 * xh[it].w;
                 ag[it].x += dyv[it].x * xh[it].x; ag[it].y += dyv[it].y * xh[it].y;
@@ -118,31 +120,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         }
         const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
 #pragma unroll
-        for (int it = 0; it < LN_MAXV; ++it) {
+        for (int it = 0; it < NV; ++it) {
             const int c = lane * 4 + it * 256;
             if (c < D) {
+                const float4 g = *(const float4*)(gamma + c);
                 float4 o;
-                o.x = rs * (dyv[it].x * g[it].x - m1 - xh[it].x * m2);
-                o.y = rs * (dyv[it].y * g[it].y - m1 - xh[it].y * m2);
-                o.z = rs * (dyv[it].z * g[it].z - m1 - xh[it].z * m2);
-                o.w = rs * (dyv[it].w * g[it].w - m1 - xh[it].w * m2);
+                o.x = rs * (dyv[it].x * g.x - m1 - xh[it].x * m2);
+                o.y = rs * (dyv[it].y * g.y - m1 - xh[it].y * m2);
+                o.z = rs * (dyv[it].z * g.z - m1 - xh[it].z * m2);
+                o.w = rs * (dyv[it].w * g.w - m1 - xh[it].w * m2);
                 if (dres) {
                     const float4 r = *(const float4*)(dres + (size_t)row * D + c);
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                 }
                 if (dxf) *(float4*)(dxf + (size_t)row * D + c) = o;
                 if (dxb) *(uint2*)(dxb + (size_t)row * D + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
-                ax[it].x += o.x; ax[it].y += o.y; ax[it].z += o.z; ax[it].w += o.w;
+                if (SUMX) { ax[it].x += o.x; ax[it].y += o.y; ax[it].z += o.z; ax[it].w += o.w; }
             }
         }
     }
-    if (!dgamma && !dxsum) return;
+    if (!dgamma && !SUMX) return;
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
         const int c = lane * 4 + it * 256;
         *(float4*)&red[0][wave][c] = ag[it];
         *(float4*)&red[1][wave][c] = ab[it];
-        *(float4*)&red[2][wave][c] = ax[it];
+        if (SUMX) *(float4*)&red[SUMX ? 2 : 0][wave][c] = ax[it];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
@@ -150,8 +153,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
             atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
             atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
         }
-        if (dxsum) atomicAdd(dxsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+        if (SUMX) atomicAdd(dxsum + c, red[SUMX ? 2 : 0][0][c] + red[SUMX ? 2 : 0][1][c] + red[SUMX ? 2 : 0][2][c] + red[SUMX ? 2 : 0][3][c]);
     }
+}
+
+template <bool DY_BF16, int NV>
+static void launch_ln_bwd(int blocks, hipStream_t st, const void* dy, const float* x, const float* gamma, const float* mean,
+                          const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma, float* dbeta, int M,
+                          int D, float* dx_colsum) {
+    if (dx_colsum)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, true>), dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres, dx_f32,
+                           dx_bf16, dgamma, dbeta, M, D, dx_colsum);
+    else
+        hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, false>), dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres, dx_f32,
+                           dx_bf16, dgamma, dbeta, M, D, dx_colsum);
 }
 
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
@@ -161,13 +176,15 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     SIG_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SIG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
     int blocks = sig_ceil_div(M, 4);
-    if (blocks > 1024) blocks = 1024;
-    if (dy_is_bf16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum);
-    else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum);
+    if (blocks > 2048) blocks = 2048;
+    const int nv = (D + 255) / 256;
+#define SIG_LN(BF, NV_) launch_ln_bwd<BF, NV_>(blocks, st, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum)
+    if (dy_is_bf16) {
+        if (nv == 1) SIG_LN(true, 1); else if (nv == 2) SIG_LN(true, 2); else if (nv == 3) SIG_LN(true, 3); else SIG_LN(true, 4);
+    } else {
+        if (nv == 1) SIG_LN(false, 1); else if (nv == 2) SIG_LN(false, 2); else if (nv == 3) SIG_LN(false, 3); else SIG_LN(false, 4);
+    }
+#undef SIG_LN
     SIG_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }
@@ -211,6 +228,35 @@ int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int 
     SIG_CHECK_ARG(src && dst && rows > 0 && cols > 0, "transpose_cast: bad arguments");
     hipLaunchKernelGGL(transpose_cast_kernel, dim3(sig_ceil_div(cols, 64), sig_ceil_div(rows, 64)), dim3(256), 0, st, src, dst, rows, cols);
     SIG_CHECK_LAUNCH("transpose_cast");
+    return 0;
+}
+
+// All transposed weight copies of a step in ONE launch: table[d] = {src f32*, dst bf16*, rows, cols} (as int64),
+// tile_start[d] = first 64x64 tile of matrix d in the flattened grid (tile_start[n] = total).
+__global__ __launch_bounds__(256) void transpose_cast_multi_kernel(const long long* __restrict__ table, const int* __restrict__ tile_start, int n) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const float* src = (const float*)table[lo * 4 + 0];
+    bf16_t* dst = (bf16_t*)table[lo * 4 + 1];
+    const int rows = (int)table[lo * 4 + 2], cols = (int)table[lo * 4 + 3];
+    const int t = b - tile_start[lo], tx_n = (cols + 63) >> 6;
+    const int r0 = (t / tx_n) * 64, c0 = (t % tx_n) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4)
+        tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(size_t)(r0 + r) * cols + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (c0 + c < cols && r0 + tx < rows) dst[(size_t)(c0 + c) * rows + r0 + tx] = f2bf(tile[tx][c]);
+}
+int sig_launch_transpose_cast_multi(const long long* table, const int* tile_start, int n, int total_tiles, hipStream_t st) {
+    SIG_CHECK_ARG(table && tile_start && n > 0 && total_tiles > 0, "transpose_cast_multi: bad arguments");
+    hipLaunchKernelGGL(transpose_cast_multi_kernel, dim3(total_tiles), dim3(256), 0, st, table, tile_start, n);
+    SIG_CHECK_LAUNCH("transpose_cast_multi");
     return 0;
 }
 

@@ -178,6 +178,7 @@ class HipPath:
         base = "clip_vision_encoder.base."
         self._byname = fl.byname
         self._transposed: Dict[str, torch.Tensor] = {}
+        self._tt = None
 
         def T(name, rows, cols):   # storage for the transposed bf16 copy of a [rows, cols] matrix
             t = torch.zeros(cols, rows, dtype=BF, device=dev)
@@ -272,14 +273,24 @@ class HipPath:
         fl, st = self.flat, _stream()
         if cast:
             _lib.call("sig_cast_bf16", fl.data.data_ptr(), fl.bf16.data_ptr(), fl.total, st)
-        for name, t in self._transposed.items():
-            src = self._byname[name].data
-            r, c = (src.shape[0], src.numel() // src.shape[0])
-            _lib.call("sig_transpose_cast_bf16", src.data_ptr(), t.data_ptr(), r, c, st)
-        if self.sim_p is not None:
-            w = self._byname[self._sim_in_w].data
-            _lib.call("sig_transpose_cast_bf16", w[:512].data_ptr(), self._sim_T["q"].data_ptr(), 512, 512, st)
-            _lib.call("sig_transpose_cast_bf16", w[512:].data_ptr(), self._sim_T["kv"].data_ptr(), 1024, 512, st)
+        if self._tt is None:   # descriptor table of every transposed copy (pointers are stable: flat buffers persist)
+            rows = []
+            for name, t in self._transposed.items():
+                src = self._byname[name].data
+                rows.append((src.data_ptr(), t.data_ptr(), src.shape[0], src.numel() // src.shape[0]))
+            if self.sim_p is not None:
+                w = self._byname[self._sim_in_w].data
+                rows.append((w[:512].data_ptr(), self._sim_T["q"].data_ptr(), 512, 512))
+                rows.append((w[512:].data_ptr(), self._sim_T["kv"].data_ptr(), 1024, 512))
+            starts, tot = [], 0
+            for _, _, r, c in rows:
+                starts.append(tot)
+                tot += ((r + 63) // 64) * ((c + 63) // 64)
+            starts.append(tot)
+            self._tt = (torch.tensor(rows, dtype=torch.int64, device=fl.device),
+                        torch.tensor(starts, dtype=torch.int32, device=fl.device), len(rows), tot)
+        table, starts, n, tot = self._tt
+        _lib.call("sig_transpose_cast_multi", table.data_ptr(), starts.data_ptr(), n, tot, st)
 
     # ------------------------------------------------------------------ backbone
     def _alloc_vit(self, S, B, train):
