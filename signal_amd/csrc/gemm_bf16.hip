@@ -100,64 +100,94 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
         }
     }
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = fr within the 16-row tile, n = 4g.. within the tile ----
-    f32x4_t csum[4];
+    // ---- epilogue ----
+    // The MFMA result has a lane holding 4 columns of 16 DIFFERENT rows: storing it directly is 16 (32 with the saved
+    // pre-activation) store instructions per lane that each touch 16 rows x 32 B -- partial cache lines and a
+    // store-issue-bound tail that cost about as much as the whole K = 768 main loop (cdna guide T21).  Instead the
+    // wave transposes its 64x64 f32 sub-tile through the now idle LDS (two 32-row passes, 68-float padded rows:
+    // conflict-free b128 writes and reads) so a lane owns 8 CONSECUTIVE columns of one row: half the store
+    // instructions, each a full 128-B (bf16) / 256-B (f32) row segment per 8 lanes.
+    __syncthreads();                                   // every wave is done reading operand fragments
+    float* stg = (float*)(smem + wave * (32 * 68 * 4));  // this wave's private staging area
+    const int t8 = lane & 7, tr = lane >> 3;           // 8 lanes per row, 8 rows per instruction
+    const int n = n0 + wn + t8 * 8;
+    float bias8[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) csum[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_BIAS_GELU_BF16 ||
+        EPI == SIG_EPI_BIAS_GELUERF_BF16) {
+        const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm + i * 16 + fr;
-        if (m >= p.M) continue;
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
+    float csum[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn + j * 16 + g * 4;
-            f32x4_t v = acc[i][j];
-            if (EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 ||
-                EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) {
-                const f32x4_t b = *(const f32x4_t*)(p.bias + n);
-                v += b;
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(f32x4_t*)(stg + (ii * 16 + fr) * 68 + j * 16 + g * 4) = acc[half * 2 + ii][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: in-order LDS, no barrier needed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = q * 8 + tr;
+            const int m = m0 + wm + half * 32 + row;
+            float v[8];
+            {
+                const f32x4_t v0 = *(const f32x4_t*)(stg + row * 68 + t8 * 8), v1 = *(const f32x4_t*)(stg + row * 68 + t8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
             }
+            if (m >= p.M) continue;
             if (EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
-                const f32x4_t r = *(const f32x4_t*)(p.res + (size_t)m * p.ldr + n);
-                v += r;
+                const float* r = p.res + (size_t)m * p.ldr + n;
+                const f32x4_t r0 = *(const f32x4_t*)r, r1 = *(const f32x4_t*)(r + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
             }
             if (EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) {
-                if (p.aux) {  // pre-activation kept for backward
-                    uint2 u2 = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                    *(uint2*)((bf16_t*)p.aux + (size_t)m * p.ldaux + n) = u2;
-                }
+                if (p.aux)   // pre-activation kept for backward
+                    *(uint4*)((bf16_t*)p.aux + (size_t)m * p.ldaux + n) =
+                        make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = EPI == SIG_EPI_BIAS_GELU_BF16 ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = EPI == SIG_EPI_BIAS_GELU_BF16 ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
             }
             if (EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_DGELUERF_BF16) {
-                const uint2 u2 = *(const uint2*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
-                const float uu[4] = {bf2f((bf16_t)(u2.x & 0xffff)), bf2f((bf16_t)(u2.x >> 16)), bf2f((bf16_t)(u2.y & 0xffff)),
-                                     bf2f((bf16_t)(u2.y >> 16))};
+                const uint4 u = *(const uint4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(uu[e]) : gelu_erf_grad_f(uu[e]);
+                for (int e = 0; e < 4; ++e) {
+                    const float u0 = bf2f((bf16_t)(w[e] & 0xffff)), u1 = bf2f((bf16_t)(w[e] >> 16));
+                    v[2 * e] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(u0) : gelu_erf_grad_f(u0);
+                    v[2 * e + 1] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(u1) : gelu_erf_grad_f(u1);
+                }
             }
             if (EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
-                *(f32x4_t*)((float*)p.out + (size_t)m * p.ldo + n) = v;
+                float* o = (float*)p.out + (size_t)m * p.ldo + n;
+                *(f32x4_t*)o = (f32x4_t){v[0], v[1], v[2], v[3]};
+                *(f32x4_t*)(o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
             } else {
-                uint2 o2 = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = o2;
+                *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) =
+                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
             }
-            csum[j] += v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += v[e];
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the second pass overwrites the area
     }
     // optional bias-gradient by-product: column sums of what was just written (this wave's 64 rows x 64 columns)
     if (p.colsum) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = csum[j][e];
-                t += __shfl_xor(t, 1, 64);
-                t += __shfl_xor(t, 2, 64);
-                t += __shfl_xor(t, 4, 64);
-                t += __shfl_xor(t, 8, 64);
-                if (fr == 0) atomicAdd(p.colsum + n0 + wn + j * 16 + g * 4 + e, t);
-            }
+        for (int e = 0; e < 8; ++e) {
+            float t = csum[e];
+            t += __shfl_xor(t, 8, 64);
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (tr == 0) atomicAdd(p.colsum + n + e, t);
+        }
     }
 }
 
@@ -235,7 +265,7 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
 int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st) {
     SIG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     SIG_CHECK_ARG((p.N & 127) == 0 && (p.K & 63) == 0, "gemm_nt: N=%d must be a multiple of 128 and K=%d of 64", p.N, p.K);
-    SIG_CHECK_ARG((p.lda & 7) == 0 && (p.ldb & 7) == 0 && (p.ldo & 3) == 0, "gemm_nt: leading dims must keep 16-B alignment");
+    SIG_CHECK_ARG((p.lda & 7) == 0 && (p.ldb & 7) == 0 && (p.ldo & 7) == 0, "gemm_nt: leading dims must keep 16-B alignment");
     SIG_CHECK_ARG(p.lda >= p.K && p.ldb >= p.K && p.ldo >= p.N, "gemm_nt: leading dimension smaller than the row");
     SIG_CHECK_ARG(p.A && p.Bt && p.out, "gemm_nt: null operand");
     switch (epi) {
