@@ -188,7 +188,7 @@ def main():
         "config": {"workload": {"fwd_sim": "configs[1]: three-stream ViT-B/16 forward + SIM, RGBNT201 256x128, random init",
                                 "train": "configs[2]: full Signal (SIM+GAM+LAM) train step, RGBNT201 256x128, random init"}[args.workload],
                    "batch_per_gpu": B, "global_batch": B * world, "tokens_per_image": 129, "parallelism": parallelism},
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<BIAS_GELU_BF16> (c_fc, M=%d N=%d K=%d)" % (3 * B * 129, Fd, D),
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<BIAS_GELU_BF16> (c_fc, M=%d N=%d K=%d)" % (3 * B * 129, Fd, D),
                      "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                      "launches": n.value, "avg_us": round(ms.value / max(n.value, 1) * 1e3, 2)},

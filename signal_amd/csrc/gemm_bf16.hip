@@ -9,6 +9,10 @@
 // per-lane SOURCE address (the DMA destination is lane-linear) so fragment reads are conflict-free.
 // fp32 accumulation; epilogues fuse bias / residual / QuickGELU / QuickGELU' so the [M, 768..3072]
 // activations make one HBM round trip per contraction.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "sig_common.h"
 #include "sig_kernels.h"
 
@@ -28,6 +32,13 @@ __device__ __forceinline__ float gelu_erf_f(float u) { return 0.5f * u * (1.0f +
 __device__ __forceinline__ float gelu_erf_grad_f(float u) {
     return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
 }
+
+#ifdef SIG_GEMM_STAMPS   // diagnostic build only (tools/gemm_stamps.py): where does a tile's time go?
+__device__ unsigned long long g_stamps[4 * 8192];
+extern "C" int sig_debug_read_stamps(unsigned long long* out, int nblocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4 * nblocks) == hipSuccess ? 0 : 2;
+}
+#endif
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
@@ -76,11 +87,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+#ifdef SIG_GEMM_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+#define SIG_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+    SIG_STAMP(ts0);
+#else
+#define SIG_STAMP(v)
+#endif
     const int nk = p.K >> 6;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // step kt landed for every wave; every wave is done reading the other buffer
+#ifdef SIG_GEMM_STAMPS
+        if (kt == 0) SIG_STAMP(ts1);
+#endif
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* s = smem + (kt & 1) * 32768;
 #pragma unroll
@@ -100,6 +121,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
         }
     }
 
+#ifdef SIG_GEMM_STAMPS
+    SIG_STAMP(ts2);
+#endif
     // ---- epilogue ----
     // The MFMA result has a lane holding 4 columns of 16 DIFFERENT rows: storing it directly is 16 (32 with the saved
     // pre-activation) store instructions per lane that each touch 16 rows x 32 B -- partial cache lines and a
@@ -189,6 +213,259 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
             if (tr == 0) atomicAdd(p.colsum + n + e, t);
         }
     }
+#ifdef SIG_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SIG_STAMP(ts3);
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_stamps[blockIdx.x * 4 + 0] = ts0; g_stamps[blockIdx.x * 4 + 1] = ts1;
+        g_stamps[blockIdx.x * 4 + 2] = ts2; g_stamps[blockIdx.x * 4 + 3] = ts3;
+    }
+#endif
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4), 128x64 per wave, phase-pipelined.
+// Why: the 128x128 kernel's main loop sits on the CU's LDS port -- 64 KB of DMA writes + 128 KB of fragment reads per
+// K-step pair ~ 1530 cycles (measured 1507, tools/gemm_stamps.py) for 1024 cycles of MFMA.  A 128x64 wave tile needs 12
+// fragment reads per 32 MFMAs instead of 16, and a 256x256 block half the DMA bytes per FLOP: 1792 LDS cycles per
+// 2048 MFMA cycles.  That only pays if the 8 waves do NOT burst DMA issue, reads and MFMAs in lockstep, so every K-step
+// is cut into 4 phases of 16 MFMAs; in each phase a wave also reads the fragments of the NEXT phase into the other
+// register set and issues 2 of its 8 DMA pieces for the next K-stage:
+//     P0: MFMA(k0, rows lo)   read A(k0,hi)              DMA B0..B3 of the next stage
+//     P1: MFMA(k0, rows hi)   read A(k1,lo), B(k1)
+//     P2: MFMA(k1, rows lo)   read A(k1,hi)
+//     -- s_waitcnt vmcnt(0) lgkmcnt(0); barrier: next stage landed, this stage fully read --
+//     P3: MFMA(k1, rows hi)   read A'(k0,lo), B'(k0) from the NEXT stage      DMA A0..A3 of the stage after
+// (all DMA is issued in P3/P0: a piece needs ~900+ cycles to land, a phase lasts ~600)
+// One barrier per K-step; LDS image and swizzle as in the 128x128 kernel; same epilogues (LDS-transposed stores).
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
+    constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = p.N >> 8, tm = gridDim.x / tn, wb = p.band;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int per = tm * wb, bnd = id / per, rr = id - bnd * per;
+    const int tile_m = rr / wb, tile_n = bnd * wb + (rr - tile_m * wb);
+    const int m0 = tile_m << 8, n0 = tile_n << 8;
+
+    // DMA pieces of this wave: A rows (wave*4+j)*8.., B rows likewise (256 rows = 32 pieces each, 8 waves x 4)
+    const bf16_t* ag[4];
+    const bf16_t* bg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        ag[j] = p.A + (size_t)(m0 + r) * p.lda + c * 8;
+        bg[j] = p.Bt + (size_t)(n0 + r) * p.ldb + c * 8;
+    }
+    auto dma_a = [&](int j, int kt, int stage) { glds16_untracked(ag[j] + kt * 64, smem + stage * STAGE + (wave * 4 + j) * 1024); };
+    auto dma_b = [&](int j, int kt, int stage) { glds16_untracked(bg[j] + kt * 64, smem + stage * STAGE + BM * 128 + (wave * 4 + j) * 1024); };
+
+    const int fr = lane & 15, g = lane >> 4, sw = fr >> 1;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ch = (((ks << 2) | g) ^ sw) << 4;
+        aoff[ks] = (wm + fr) * 128 + ch;
+        boff[ks] = BM * 128 + (wn + fr) * 128 + ch;
+    }
+    // Fragment reads are inline asm and their waits are issued by hand (counted, and tied to the fragment registers so
+    // no MFMA can be scheduled above its wait).  Left to the compiler, the register allocator recycles the destination
+    // of an in-flight ds_read as an MFMA result register and the WAW hazard turns every wait into lgkmcnt(0).
+    bf16x8_t aX[4], aY[4], bX[4], bY[4];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#define SIG_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    auto rd_a = [&](int stage, int ks, auto half_c, bf16x8_t (&a)[4]) {
+        constexpr int H = decltype(half_c)::value;
+        const unsigned ad = lds0 + stage * STAGE + aoff[ks];
+        SIG_RD128(a[0], ad, (H * 4 + 0) * 2048);
+        SIG_RD128(a[1], ad, (H * 4 + 1) * 2048);
+        SIG_RD128(a[2], ad, (H * 4 + 2) * 2048);
+        SIG_RD128(a[3], ad, (H * 4 + 3) * 2048);
+    };
+    auto rd_b = [&](int stage, int ks, bf16x8_t (&b)[4]) {
+        const unsigned ad = lds0 + stage * STAGE + boff[ks];
+        SIG_RD128(b[0], ad, 0);
+        SIG_RD128(b[1], ad, 2048);
+        SIG_RD128(b[2], ad, 4096);
+        SIG_RD128(b[3], ad, 6144);
+    };
+#define SIG_WAIT4(n, a) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#define SIG_WAIT8(n, a, b)                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), \
+                 "+v"(b[2]), "+v"(b[3]))
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int half, const bf16x8_t (&a)[4], const bf16x8_t (&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[half * 4 + i][j], 0, 0, 0);
+    };
+
+    const int nk = p.K >> 6;
+#ifdef SIG_GEMM_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    SIG_STAMP(ts0);
+#endif
+    // prologue: stage 0 complete, first fragments, first two pieces of stage 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dma_a(j, 0, 0); dma_b(j, 0, 0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#ifdef SIG_GEMM_STAMPS
+    SIG_STAMP(ts1);
+#endif
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    rd_a(0, 0, H0{}, aX);
+    rd_b(0, 0, bX);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_a(j, 1, 1);
+    // one K-step; MORE / MORE2 are compile-time so the steady-state body is a single basic block; the last two steps are
+    // peeled copies.  Needs nk >= 2.  LDS returns in order, so "lgkmcnt(n)" = everything but the newest n reads landed.
+    auto step = [&](int kt, auto more_c, auto more2_c) {
+        constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+        const int st = kt & 1;
+        // P0: outstanding aX,bX (8) + aY (4)
+        rd_a(st, 0, H1{}, aY);
+        if (MORE) { dma_b(0, kt + 1, st ^ 1); dma_b(1, kt + 1, st ^ 1); dma_b(2, kt + 1, st ^ 1); dma_b(3, kt + 1, st ^ 1); }
+        SIG_WAIT8(4, aX, bX);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, aX, bX);
+        __builtin_amdgcn_sched_barrier(0);
+        // P1: outstanding aY (4) + aX,bY (8)
+        rd_a(st, 1, H0{}, aX);
+        rd_b(st, 1, bY);
+        SIG_WAIT4(8, aY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, aY, bX);
+        __builtin_amdgcn_sched_barrier(0);
+        // P2: outstanding aX,bY (8) + aY (4)
+        rd_a(st, 1, H1{}, aY);
+        SIG_WAIT8(4, aX, bY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, aX, bY);
+        __builtin_amdgcn_sched_barrier(0);
+        // stage boundary: this wave's DMA pieces of the next stage landed, all its reads of this stage returned
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(aY[0]), "+v"(aY[1]), "+v"(aY[2]), "+v"(aY[3])::"memory");
+        __builtin_amdgcn_s_barrier();
+        // P3
+        if (MORE) {
+            rd_a(st ^ 1, 0, H0{}, aX);
+            rd_b(st ^ 1, 0, bX);
+        }
+        if (MORE2) { dma_a(0, kt + 2, st); dma_a(1, kt + 2, st); dma_a(2, kt + 2, st); dma_a(3, kt + 2, st); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, aY, bY);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    for (int kt = 0; kt < nk - 2; ++kt) step(kt, T_{}, T_{});
+    step(nk - 2, T_{}, F_{});
+    step(nk - 1, F_{}, F_{});
+
+#ifdef SIG_GEMM_STAMPS
+    SIG_STAMP(ts2);
+#endif
+    // ---- epilogue: 8 passes of 16 rows through this wave's private LDS area (see the 128x128 kernel) ----
+    // No s_waitcnt between a pass's staging writes and its reads, nor before the next pass overwrites the area: the
+    // LDS executes one wave's instructions in order and the area is private to the wave, so the compiler is free to
+    // overlap the next pass's staging with this pass's conversion and stores.
+    __builtin_amdgcn_s_barrier();   // every wave has finished reading operand fragments (no DMA is outstanding)
+    float* stg = (float*)(smem + wave * (16 * 68 * 4));
+    const int t8 = lane & 7, tr = lane >> 3;
+    const int n = n0 + wn + t8 * 8;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_BIAS_GELU_BF16 ||
+        EPI == SIG_EPI_BIAS_GELUERF_BF16) {
+        const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4_t*)(stg + fr * 68 + j * 16 + g * 4) = acc[i][j];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = q * 8 + tr;
+            const int m = m0 + wm + i * 16 + row;
+            float v[8];
+            {
+                const f32x4_t v0 = *(const f32x4_t*)(stg + row * 68 + t8 * 8), v1 = *(const f32x4_t*)(stg + row * 68 + t8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+            }
+            if (m >= p.M) continue;
+            if (EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
+                const float* r = p.res + (size_t)m * p.ldr + n;
+                const f32x4_t r0 = *(const f32x4_t*)r, r1 = *(const f32x4_t*)(r + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            }
+            if (EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) {
+                if (p.aux)
+                    *(uint4*)((bf16_t*)p.aux + (size_t)m * p.ldaux + n) =
+                        make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = EPI == SIG_EPI_BIAS_GELU_BF16 ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+            }
+            if (EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_DGELUERF_BF16) {
+                const uint4 u = *(const uint4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u0 = bf2f((bf16_t)(w[e] & 0xffff)), u1 = bf2f((bf16_t)(w[e] >> 16));
+                    v[2 * e] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(u0) : gelu_erf_grad_f(u0);
+                    v[2 * e + 1] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(u1) : gelu_erf_grad_f(u1);
+                }
+            }
+            if (EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
+                float* o = (float*)p.out + (size_t)m * p.ldo + n;
+                *(f32x4_t*)o = (f32x4_t){v[0], v[1], v[2], v[3]};
+                *(f32x4_t*)(o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+            } else {
+                *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) =
+                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        }
+    }
+    if (p.colsum) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = csum[e];
+            t += __shfl_xor(t, 8, 64);
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (tr == 0) atomicAdd(p.colsum + n + e, t);
+        }
+    }
+#ifdef SIG_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SIG_STAMP(ts3);
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_stamps[blockIdx.x * 4 + 0] = ts0; g_stamps[blockIdx.x * 4 + 1] = ts1;
+        g_stamps[blockIdx.x * 4 + 2] = ts2; g_stamps[blockIdx.x * 4 + 3] = ts3;
+    }
+#endif
 }
 
 // ---- live timing of one GEMM shape (bench.py's roofline leg): HIP events on the launch stream ----
@@ -232,8 +509,9 @@ int sig_prof_end_impl(double* total_ms, int* launches, double* flops) {
     return 0;
 }
 
-static int choose_band(int tn, int K) {
-    int wmax = (int)(2400000LL / (256LL * K));
+
+static int choose_band(int tn, int K, int BN) {
+    int wmax = (int)(2400000LL / (2LL * BN * K));
     if (wmax < 1) wmax = 1;
     for (int nb = 1; nb <= tn; ++nb)
         if (tn % nb == 0 && tn / nb <= wmax) return tn / nb;
@@ -243,16 +521,34 @@ static int choose_band(int tn, int K) {
 template <int EPI>
 static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     SigGemmNT p = p_in;
-    p.band = choose_band(p.N >> 7, p.K);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_done = true;
-    }
-    const int tiles = ((p.M + 127) >> 7) * (p.N >> 7);
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("SIG_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    // 256x256 phase-pipelined kernel when the problem fills the chip with it and the 128-row padding of the token
+    // buffers happens to be a 256 multiple (M = 24768 -> 24832 = 97 * 256); otherwise the 128x128 kernel
+    const int mp = ((p.M + 127) >> 7) << 7;
+    const bool can256 = (p.N & 255) == 0 && (mp & 255) == 0 && p.K >= 128;
+    bool big = can256 && (mp >> 8) * (p.N >> 8) >= 512;
+    if (force == 128) big = false;
+    if (force == 256) big = can256;
     const bool timed = g_prof.on && g_prof.epi == EPI && g_prof.N == p.N && g_prof.K == p.K && g_prof.used + 2 <= g_prof.ev.size();
     if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tiles), dim3(256), 65536, st, p);
+    if (big) {
+        static bool attr256 = false;
+        if (!attr256) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            attr256 = true;
+        }
+        p.band = choose_band(p.N >> 8, p.K, 256);
+        hipLaunchKernelGGL(gemm_nt256_kernel<EPI>, dim3((mp >> 8) * (p.N >> 8)), dim3(512), 131072, st, p);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            attr_done = true;
+        }
+        p.band = choose_band(p.N >> 7, p.K, 128);
+        hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3((mp >> 7) * (p.N >> 7)), dim3(256), 65536, st, p);
+    }
     if (timed) {
         (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
         g_prof.used += 2;

@@ -60,6 +60,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// Same transfer issued through inline asm.  The compiler's waitcnt pass models an LDS-DMA as an LGKM event, so with a
+// builtin DMA in flight every fragment wait becomes `s_waitcnt lgkmcnt(0)`; the hardware counts it in vmcnt only
+// (tools/micro/lgkm_dma.hip: lgkmcnt(0) returns 114 cycles after a cold DMA + ds_read, vmcnt(0) 870 cycles later).
+// Issued this way the DMA is invisible to that pass: the CALLER must `s_waitcnt vmcnt(0)` before anyone reads the
+// destination and before any compiler-tracked global load is consumed (its counted vmcnt would be off).
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, void* lds_wave_base) {
+    const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");   // m0 is reserved: not clobberable; kernels using this helper must not mix it with glds16()
+}
 // transposed LDS read: per 16-lane group a 4x16 block of 16-bit elements, delivered column-major
 __device__ __forceinline__ bf16x4_t lds_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)p);

@@ -35,7 +35,7 @@ def padded(t, ops):
     return out
 
 
-GEMM_SHAPES = [(774, 384, 128), (1000, 768, 3072), (4128, 2304, 768), (129, 128, 64)]
+GEMM_SHAPES = [(774, 384, 128), (1000, 768, 3072), (4128, 2304, 768), (129, 128, 64), (2000, 512, 192)]
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic: builds a PRIVATE copy of the library with -DSIG_GEMM_STAMPS (s_memtime stamps at kernel start, first data
+landed, main loop end, stores drained) and prints the per-tile time split of the qkv / c_fc / c_proj GEMMs. GPU box only;
+the shipped library never contains the stamps."""
+import ctypes, os, shutil, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "signal_amd", "csrc")
+tmp = tempfile.mkdtemp()
+lib = os.path.join(tmp, "libsignal_hip_stamps.so")
+srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hip") and f != "sim.hip"]
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffast-math",
+       "-fno-finite-math-only", "-DSIG_GEMM_STAMPS", "-shared", "-o", lib, *srcs, os.path.join(csrc, "sim.hip")]
+subprocess.run(cmd, check=True, capture_output=True)
+import torch
+from signal_amd import _lib, ops
+_lib.LIB_PATH = lib
+_lib._lib = None
+L = _lib.load()
+dev = torch.device("cuda:0")
+M = 24768; Mp = ops.pad_rows(M)
+for name, n, k, epi in [("qkv", 2304, 768, ops.BIAS_BF16), ("c_fc", 3072, 768, ops.BIAS_GELU_BF16), ("c_proj", 768, 3072, ops.BIAS_RES_F32)]:
+    a = torch.randn(Mp, k, device=dev).to(torch.bfloat16); w = (torch.randn(n, k, device=dev) * .02).to(torch.bfloat16)
+    bias = torch.randn(n, device=dev); f32 = epi == ops.BIAS_RES_F32
+    out = torch.zeros(Mp, n, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    aux = torch.zeros(Mp, n, device=dev, dtype=torch.bfloat16) if epi == ops.BIAS_GELU_BF16 else None
+    for _ in range(3):
+        ops.gemm_nt(a, w, M, epi, out, bias=bias, res=out if f32 else None, aux=aux)
+    torch.cuda.synchronize()
+    T = int(os.environ.get('SIG_GEMM_TILE', '128'))
+    nb = min(8192, (Mp // T) * (n // T))
+    buf = (ctypes.c_ulonglong * (4 * nb))()
+    assert L.sig_debug_read_stamps(buf, nb) == 0
+    t = torch.tensor(list(buf), dtype=torch.float64).view(nb, 4)
+    t = t[(t[:, 0] > 0)]
+    pro, loop, epi_t = (t[:, 1] - t[:, 0]), (t[:, 2] - t[:, 1]), (t[:, 3] - t[:, 2])
+    span = (t[:, 3].max() - t[:, 0].min())
+    print(f"{name:7s} tiles {nb:5d}  per-tile cycles: prologue {pro.median():8.0f}  main loop {loop.median():8.0f} ({loop.median()/(k//64):6.0f}/k-step)"
+          f"  epilogue+drain {epi_t.median():8.0f}  total {(t[:,3]-t[:,0]).median():8.0f}")
+shutil.rmtree(tmp, ignore_errors=True)

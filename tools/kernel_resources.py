@@ -22,5 +22,5 @@ for src in (sys.argv[1:] or B.sources()):
         elif ":" in t:
             k, v = t.split(":", 1)
             if k.strip() in ("VGPRs", "AGPRs", "ScratchSize [bytes/lane]", "VGPRs Spill", "LDS Size [bytes/block]", "Occupancy [waves/SIMD]", "SGPRs"):
-                cur[k.strip().split(" ")[0]] = v.strip()
+                cur[k.strip().replace(" ", "_").split("_[")[0]] = v.strip()
     if cur: print(cur)
