@@ -33,6 +33,124 @@ __device__ __forceinline__ float gelu_erf_grad_f(float u) {
     return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-only epilogue (no LDS).  With the swapped MFMA operands lane (fr = lane & 15, g = lane >> 4) holds, for
+// 16-row group i and 16-column group j, the 4 CONSECUTIVE columns j*16 + g*4 .. +3 of row i*16 + fr.
+//  * everything elementwise (bias, residual, GELU, GELU') happens in that layout;
+//  * f32 outputs are stored from it directly: 16 B per lane, 64 B runs per row and instruction;
+//  * bf16 outputs are packed (2 dwords per (i, j)) and exchanged between lanes g and g^1 with v_permlane16_swap_b32
+//    (gfx950; tools/micro/permlane16_swap.hip): for a column-group pair (2jp, 2jp+1) the even-g lane ends up with columns
+//    (2jp)*16 + (g>>1)*8 .. +7 and the odd-g lane with (2jp+1)*16 + (g>>1)*8 .. +7 -> one 16-B store per lane, the
+//    same store count as a transposed tile but without ~2 x tile bytes through ds_write_b128 (79 B/clk/CU);
+//  * the saved pre-activation u of the GELU' epilogues is loaded 16 B wide in the swapped layout and un-swapped (the
+//    exchange is an involution).
+// Rows >= M are computed (the swaps need every lane) but neither loaded, stored nor summed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lane_swap16(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)[TM][TN], int m_base, int n_base, int lane) {
+    static_assert(TN % 2 == 0, "column groups are exchanged in pairs");
+    constexpr bool HAS_BIAS = EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 ||
+                              EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16;
+    constexpr bool HAS_RES = EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32;
+    constexpr bool OUT_F32 = EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || HAS_RES;
+    constexpr bool GELU_FWD = EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16;
+    constexpr bool GELU_BWD = EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_DGELUERF_BF16;
+    constexpr bool QUICK = EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_DGELU_BF16;
+    const int fr = lane & 15, g = lane >> 4;
+    const int nc = n_base + g * 4;                              // + j*16: this lane's 4 columns in the MFMA layout
+    const int ns = n_base + (g & 1) * 16 + (g >> 1) * 8;        // + jp*32: its 8 columns after the exchange
+    f32x4_t bias4[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bias4[j] = HAS_BIAS ? *(const f32x4_t*)(p.bias + nc + j * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t csum[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) csum[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool save_u = GELU_FWD && p.aux != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m_base + i * 16 + fr;
+        const bool live = m < p.M;
+        uint32_t pk[TN][2], pu[TN][2];
+        if (GELU_BWD) {
+#pragma unroll
+            for (int jp = 0; jp < TN / 2; ++jp) {
+                uint4 q = make_uint4(0, 0, 0, 0);
+                if (live) q = *(const uint4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + ns + jp * 32);
+                lane_swap16(q.x, q.z);
+                lane_swap16(q.y, q.w);
+                pu[2 * jp][0] = q.x; pu[2 * jp][1] = q.y;
+                pu[2 * jp + 1][0] = q.z; pu[2 * jp + 1][1] = q.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4_t x = acc[i][j] + bias4[j];
+            if (HAS_RES && live) x += *(const f32x4_t*)(p.res + (size_t)m * p.ldr + nc + j * 16);
+            if (GELU_FWD) {
+                pu[j][0] = pack2bf(x[0], x[1]);
+                pu[j][1] = pack2bf(x[2], x[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = QUICK ? quick_gelu_f(x[e]) : gelu_erf_f(x[e]);
+            }
+            if (GELU_BWD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t w = pu[j][e >> 1];
+                    const float u = bf2f((bf16_t)((e & 1) ? (w >> 16) : (w & 0xffff)));
+                    x[e] *= QUICK ? quick_gelu_grad_f(u) : gelu_erf_grad_f(u);
+                }
+            }
+            if (OUT_F32) {
+                if (live) *(f32x4_t*)((float*)p.out + (size_t)m * p.ldo + nc + j * 16) = x;
+            } else {
+                pk[j][0] = pack2bf(x[0], x[1]);
+                pk[j][1] = pack2bf(x[2], x[3]);
+            }
+            if (live) csum[j] += x;
+        }
+        if (!OUT_F32) {
+#pragma unroll
+            for (int jp = 0; jp < TN / 2; ++jp) {
+                lane_swap16(pk[2 * jp][0], pk[2 * jp + 1][0]);
+                lane_swap16(pk[2 * jp][1], pk[2 * jp + 1][1]);
+                if (live)
+                    *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + ns + jp * 32) =
+                        make_uint4(pk[2 * jp][0], pk[2 * jp][1], pk[2 * jp + 1][0], pk[2 * jp + 1][1]);
+            }
+        }
+        if (GELU_FWD) {
+#pragma unroll
+            for (int jp = 0; jp < TN / 2; ++jp) {
+                lane_swap16(pu[2 * jp][0], pu[2 * jp + 1][0]);
+                lane_swap16(pu[2 * jp][1], pu[2 * jp + 1][1]);
+                if (live && save_u)
+                    *(uint4*)((bf16_t*)p.aux + (size_t)m * p.ldaux + ns + jp * 32) =
+                        make_uint4(pu[2 * jp][0], pu[2 * jp][1], pu[2 * jp + 1][0], pu[2 * jp + 1][1]);
+            }
+        }
+    }
+    // optional bias-gradient by-product: column sums of what was just written
+    if (p.colsum) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = csum[j][e];
+                t += __shfl_xor(t, 1, 64);
+                t += __shfl_xor(t, 2, 64);
+                t += __shfl_xor(t, 4, 64);
+                t += __shfl_xor(t, 8, 64);
+                if (fr == 0) atomicAdd(p.colsum + nc + j * 16 + e, t);
+            }
+    }
+}
+
 #ifdef SIG_GEMM_STAMPS   // diagnostic build only (tools/gemm_stamps.py): where does a tile's time go?
 __device__ unsigned long long g_stamps[4 * 8192];
 extern "C" int sig_debug_read_stamps(unsigned long long* out, int nblocks) {
@@ -125,6 +243,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     SIG_STAMP(ts2);
 #endif
     // ---- epilogue ----
+    // bf16 outputs: straight from the accumulator registers (epilogue_regs above: no LDS, no barrier; qkv epilogue
+    // 5960 -> 3476 cycles per tile).  f32 outputs keep the LDS transpose below: a lane of the MFMA layout only holds 16 B
+    // of an f32 row, so register stores make 64-B runs and measured slower (c_proj 11.1k -> 18.1k cycles).
+    constexpr bool OUT_F32 = EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32;
+    if constexpr (!OUT_F32) {
+        epilogue_regs<EPI, 4, 4>(p, acc, m0 + wm, n0 + wn, lane);
+    } else {
     // The MFMA result has a lane holding 4 columns of 16 DIFFERENT rows: storing it directly is 16 (32 with the saved
     // pre-activation) store instructions per lane that each touch 16 rows x 32 B -- partial cache lines and a
     // store-issue-bound tail that cost about as much as the whole K = 768 main loop (cdna guide T21).  Instead the
@@ -212,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
             t += __shfl_xor(t, 32, 64);
             if (tr == 0) atomicAdd(p.colsum + n + e, t);
         }
+    }
     }
 #ifdef SIG_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -378,86 +504,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
 #ifdef SIG_GEMM_STAMPS
     SIG_STAMP(ts2);
 #endif
-    // ---- epilogue: 8 passes of 16 rows through this wave's private LDS area (see the 128x128 kernel) ----
-    // No s_waitcnt between a pass's staging writes and its reads, nor before the next pass overwrites the area: the
-    // LDS executes one wave's instructions in order and the area is private to the wave, so the compiler is free to
-    // overlap the next pass's staging with this pass's conversion and stores.
-    __builtin_amdgcn_s_barrier();   // every wave has finished reading operand fragments (no DMA is outstanding)
-    float* stg = (float*)(smem + wave * (16 * 68 * 4));
-    const int t8 = lane & 7, tr = lane >> 3;
-    const int n = n0 + wn + t8 * 8;
-    float bias8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if (EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_BIAS_GELU_BF16 ||
-        EPI == SIG_EPI_BIAS_GELUERF_BF16) {
-        const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
-    }
-    float csum[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *(f32x4_t*)(stg + fr * 68 + j * 16 + g * 4) = acc[i][j];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int row = q * 8 + tr;
-            const int m = m0 + wm + i * 16 + row;
-            float v[8];
-            {
-                const f32x4_t v0 = *(const f32x4_t*)(stg + row * 68 + t8 * 8), v1 = *(const f32x4_t*)(stg + row * 68 + t8 * 8 + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
-            }
-            if (m >= p.M) continue;
-            if (EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
-                const float* r = p.res + (size_t)m * p.ldr + n;
-                const f32x4_t r0 = *(const f32x4_t*)r, r1 = *(const f32x4_t*)(r + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-            }
-            if (EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) {
-                if (p.aux)
-                    *(uint4*)((bf16_t*)p.aux + (size_t)m * p.ldaux + n) =
-                        make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = EPI == SIG_EPI_BIAS_GELU_BF16 ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
-            }
-            if (EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_DGELUERF_BF16) {
-                const uint4 u = *(const uint4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
-                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u0 = bf2f((bf16_t)(w[e] & 0xffff)), u1 = bf2f((bf16_t)(w[e] >> 16));
-                    v[2 * e] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(u0) : gelu_erf_grad_f(u0);
-                    v[2 * e + 1] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(u1) : gelu_erf_grad_f(u1);
-                }
-            }
-            if (EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
-                float* o = (float*)p.out + (size_t)m * p.ldo + n;
-                *(f32x4_t*)o = (f32x4_t){v[0], v[1], v[2], v[3]};
-                *(f32x4_t*)(o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
-            } else {
-                *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) =
-                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) csum[e] += v[e];
-        }
-    }
-    if (p.colsum) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = csum[e];
-            t += __shfl_xor(t, 8, 64);
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            if (tr == 0) atomicAdd(p.colsum + n + e, t);
-        }
-    }
+    // ---- epilogue: straight from the accumulator registers, no LDS and no barrier ----
+    epilogue_regs<EPI, 8, 4>(p, acc, m0 + wm, n0 + wn, lane);
 #ifdef SIG_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SIG_STAMP(ts3);
@@ -690,6 +738,164 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(SigGemmTN p) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN, 256x256 output tile, 8 waves (2 x 4), 128(I) x 64(J) per wave = 4 x 2 MFMA 32x32x16, phase-pipelined like
+// gemm_nt256_kernel: a K-step (64 rows of m) is 4 phases of 8 MFMAs (one 16-row slab each); in every phase the wave
+// also reads the NEXT slab's 12 transposed fragments halves into the other register set (inline asm, counted waits tied
+// to the registers) and the LDS-DMA of the following stages is issued in P3 / P0 so that every piece has >= 2 phases
+// to land.  One barrier per K-step.  LDS image per operand: 64 rows x 512 B, physical chunk = chunk ^ ((row & 3) << 2)
+// (the 128-column image's swizzle: a 512-B row is two bank rows, the XOR acts on the chunk's low 4 bits).
+// Fewer, larger blocks also fill the chip better: c_fc wgrad = 36 tiles x 7 row chunks = 252 blocks on 256 CUs,
+// against 144 x 3 = 432 blocks of the 128x128 kernel on 512 slots.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(SigGemmTN p) {
+    constexpr int ROWB = 512, OPB = 64 * ROWB, STAGE = 2 * OPB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tj = p.J >> 8, ti = p.I >> 8, tiles = ti * tj;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id / tiles, t = id - split * tiles;
+    const int tile_i = t / tj, tile_j = t - tile_i * tj;
+    const int i0 = tile_i << 8, j0 = tile_j << 8;
+    const int mbeg = split * p.m_chunk;
+    int mend = mbeg + p.m_chunk;
+    if (mend > p.Mr) mend = p.Mr;
+    const int nk = (mend - mbeg) >> 6;
+    if (nk <= 0) return;
+
+    // DMA: a 1-KB piece = 2 rows x 512 B; 32 pieces per operand and stage, 4 + 4 per wave
+    const bf16_t* pg[4];
+    const bf16_t* qg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 2 + (lane >> 5);
+        const int c = (lane & 31) ^ ((r & 3) << 2);
+        pg[j] = p.P + (size_t)(mbeg + r) * p.ldp + i0 + c * 8;
+        qg[j] = p.Q + (size_t)(mbeg + r) * p.ldq + j0 + c * 8;
+    }
+    const size_t pstep = (size_t)64 * p.ldp, qstep = (size_t)64 * p.ldq;
+    auto dma_p = [&](int j, int kt, int stage) { glds16_untracked(pg[j] + kt * pstep, smem + stage * STAGE + (wave * 4 + j) * 1024); };
+    auto dma_q = [&](int j, int kt, int stage) { glds16_untracked(qg[j] + kt * qstep, smem + stage * STAGE + OPB + (wave * 4 + j) * 1024); };
+
+    // transposed-read addressing (see gemm_tn_kernel): lane = 16*G + 4*q + pp
+    const int G = lane >> 4, h = G >> 1, tq = (lane >> 2) & 3, pp = lane & 3;
+    const int wi = (wave >> 2) * 128, wj = (wave & 3) * 64;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned foff[6];   // 0..3 P column tiles, 4..5 Q column tiles
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int col = wi + a * 32 + 16 * (G & 1) + 4 * pp;
+        foff[a] = lds0 + (8 * h + tq) * ROWB + ((((col >> 3) ^ (tq << 2)) << 4) | ((pp & 1) << 3));
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = wj + b * 32 + 16 * (G & 1) + 4 * pp;
+        foff[4 + b] = lds0 + OPB + (8 * h + tq) * ROWB + ((((col >> 3) ^ (tq << 2)) << 4) | ((pp & 1) << 3));
+    }
+    struct Frags { bf16x4_t lo[6], hi[6]; };   // 0..3: P column tiles, 4..5: Q column tiles; lo = rows +0..3, hi = rows +4..7
+    Frags X, Y;
+#define SIG_RDTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    auto rd = [&](int stage, auto ks_c, Frags& f) {
+        constexpr int KS = decltype(ks_c)::value;
+        const unsigned so = stage * STAGE;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const unsigned ad = foff[a] + so;
+            SIG_RDTR(f.lo[a], ad, KS * 16 * ROWB);
+            SIG_RDTR(f.hi[a], ad, KS * 16 * ROWB + 4 * ROWB);
+        }
+    };
+#define SIG_WAITF(n, f)                                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                                \
+                 : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]), "+v"(f.lo[3]), \
+                   "+v"(f.hi[3]), "+v"(f.lo[4]), "+v"(f.hi[4]), "+v"(f.lo[5]), "+v"(f.hi[5]))
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    auto mma = [&](const Frags& f) {
+        bf16x8_t pf[4], qf[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pf[a] = __builtin_shufflevector(f.lo[a], f.hi[a], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) qf[b] = __builtin_shufflevector(f.lo[4 + b], f.hi[4 + b], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dma_p(j, 0, 0); dma_q(j, 0, 0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rd(0, K0{}, X);
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_p(j, 1, 1);
+    }
+    auto step = [&](int kt, auto more_c, auto more2_c) {
+        constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+        const int st = kt & 1;
+        // P0: X (12 reads) outstanding, Y issued behind it
+        rd(st, K1{}, Y);
+        if (MORE) { dma_q(0, kt + 1, st ^ 1); dma_q(1, kt + 1, st ^ 1); dma_q(2, kt + 1, st ^ 1); dma_q(3, kt + 1, st ^ 1); }
+        SIG_WAITF(12, X);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(X);
+        __builtin_amdgcn_sched_barrier(0);
+        // P1
+        rd(st, K2{}, X);
+        SIG_WAITF(12, Y);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(Y);
+        __builtin_amdgcn_sched_barrier(0);
+        // P2
+        rd(st, K3{}, Y);
+        SIG_WAITF(12, X);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(X);
+        __builtin_amdgcn_sched_barrier(0);
+        // stage boundary: this wave's pieces of the next stage landed, its reads of this stage returned
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(Y.lo[0]), "+v"(Y.hi[0]), "+v"(Y.lo[1]), "+v"(Y.hi[1]), "+v"(Y.lo[2]), "+v"(Y.hi[2]), "+v"(Y.lo[3]),
+                       "+v"(Y.hi[3]), "+v"(Y.lo[4]), "+v"(Y.hi[4]), "+v"(Y.lo[5]), "+v"(Y.hi[5])::"memory");
+        __builtin_amdgcn_s_barrier();
+        // P3
+        if (MORE) rd(st ^ 1, K0{}, X);
+        if (MORE2) { dma_p(0, kt + 2, st); dma_p(1, kt + 2, st); dma_p(2, kt + 2, st); dma_p(3, kt + 2, st); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(Y);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    for (int kt = 0; kt < nk - 2; ++kt) step(kt, T_{}, T_{});
+    if (nk >= 2) step(nk - 2, T_{}, F_{});
+    step(nk - 1, F_{}, F_{});
+
+    // D[row = I][col = J]: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): one register = two 128-B rows
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ii = i0 + wi + a * 32 + (e & 3) + 8 * (e >> 2) + rbase;
+                const int jj = j0 + wj + b * 32 + col;
+                atomicAdd(p.out + (size_t)ii * p.ldo + jj, acc[a][b][e]);
+            }
+}
+
 int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
     SigGemmTN p = p_in;
     SIG_CHECK_ARG(p.Mr > 0 && (p.Mr & 63) == 0, "gemm_tn: row count %d must be a positive multiple of 64 (pad rows zeroed)", p.Mr);
@@ -701,8 +907,32 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_done = true;
     }
-    const int tiles = (p.I >> 7) * (p.J >> 7);
     const int ksteps = p.Mr >> 6;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("SIG_GEMM_TN_TILE"); force = e ? atoi(e) : 0; }
+    // 256x256 tiles for the large weight gradients (one block per CU, <= 256 blocks); the rest on 128x128 tiles
+    const bool can256 = (p.I & 255) == 0 && (p.J & 255) == 0 && (p.I >> 8) * (p.J >> 8) <= 128;
+    bool big = can256 && (size_t)p.I * p.J >= (size_t)1536 * 768 && ksteps >= 64;
+    if (force == 128) big = false;
+    if (force == 256) big = can256;
+    if (big) {
+        static bool attr256 = false;
+        if (!attr256) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            attr256 = true;
+        }
+        const int tiles = (p.I >> 8) * (p.J >> 8);
+        int split = p.split > 0 ? p.split : 256 / tiles;
+        if (split < 1) split = 1;
+        if (split > ksteps) split = ksteps;
+        const int per = sig_ceil_div(ksteps, split);
+        split = sig_ceil_div(ksteps, per);
+        p.m_chunk = per * 64;
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * split), dim3(512), 131072, st, p);
+        SIG_CHECK_LAUNCH("gemm_tn256");
+        return 0;
+    }
+    const int tiles = (p.I >> 7) * (p.J >> 7);
     // every split re-adds a whole 128x128 f32 tile with atomics (64 KB per workgroup, ~1.3 TB/s chip-wide), so use the
     // FEWEST row chunks that still fill the chip once: tiles * split <= 512 resident workgroups (2 per CU)
     int split = p.split > 0 ? p.split : (512 / tiles > 0 ? 512 / tiles : 1);

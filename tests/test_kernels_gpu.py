@@ -85,7 +85,8 @@ def test_gemm_nt_epilogues(dev, m, n, k):
     assert rel_err(ob[:m].float(), ref * (s * (1 + 1.702 * uu.float() * (1 - s)))) < 4e-3
 
 
-@pytest.mark.parametrize("mr,i,j", [(128, 128, 128), (896, 384, 128), (4160, 768, 256), (24832, 256, 128)])
+@pytest.mark.parametrize("mr,i,j", [(128, 128, 128), (896, 384, 128), (4160, 768, 256), (24832, 256, 128), (8192, 1536, 768),
+                                    (4160, 2304, 768), (64, 1536, 768)])
 def test_gemm_tn(dev, mr, i, j):
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(mr + i)
