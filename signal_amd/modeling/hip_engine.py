@@ -135,6 +135,10 @@ class HipPath:
             self._pack()
 
     direct_grads = False
+    # Grad mode of the CALLER.  Inside autograd.Function.forward grad mode is always off and ctx.needs_input_grad is
+    # True for parameters even under torch.no_grad(), so the callers (make_model / align) record torch.is_grad_enabled()
+    # here right before .apply(); without it an inference forward took (and never returned) a training workspace.
+    grad_mode = True
 
     def enable_direct_grads(self):
         """Training-engine mode: every Parameter's .grad is a persistent view of flat.grad; the HIP backward
@@ -470,7 +474,7 @@ class BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hip: HipPath, cam, n_img, *args):
         imgs, params = args[:n_img], args[n_img:]
-        train = any(ctx.needs_input_grad)     # grad mode is off inside forward(); this is what autograd will ask for
+        train = hip.grad_mode and any(ctx.needs_input_grad)   # see HipPath.grad_mode
         ws = hip.vit_forward(list(imgs), cam, train)
         ctx.hip, ctx.ws, ctx.n_img, ctx.train = hip, ws, n_img, train
         M = ws["M"]
@@ -500,7 +504,7 @@ class SimFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hip: HipPath, B, tokens, *params):
-        train = any(ctx.needs_input_grad)
+        train = hip.grad_mode and any(ctx.needs_input_grad)
         tok = tokens.contiguous()   # read row-wise only, so it needs no row padding
         ws = hip.sim_forward(tok, B, train)
         ctx.hip, ctx.ws, ctx.B, ctx.shape = hip, ws, B, tokens.shape
@@ -534,7 +538,10 @@ class GamFn(torch.autograd.Function):
         tok = tokens.contiguous()
         ws = hip.gam_forward(tok, B)
         ctx.hip, ctx.ws, ctx.shape = hip, ws, tokens.shape
-        return ws["t"]["loss"][0].clone()
+        out = ws["t"]["loss"][0].clone()
+        if not (hip.grad_mode and any(ctx.needs_input_grad)):   # no backward will come: hand the workspace back now
+            hip._gam_ws[(ws["B"],)].append(ws)
+        return out
 
     @staticmethod
     def backward(ctx, dloss):
@@ -556,7 +563,7 @@ class LamFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hip: HipPath, B, tokens, *params):
-        train = any(ctx.needs_input_grad)
+        train = hip.grad_mode and any(ctx.needs_input_grad)
         tok = tokens.contiguous()
         ws = hip.lam_forward(tok, B, train)
         ctx.hip, ctx.ws, ctx.tok = hip, ws, tok

@@ -118,12 +118,14 @@ class Signal(nn.Module):
                 raise ValueError(f"cam_label has {cam.numel()} entries for a batch of {B}")
         hip = self.hip
         vit_params = [hip.flat.byname[n] for n in hip.vit_param_names]
+        hip.grad_mode = torch.is_grad_enabled()
         tokens = BackboneFn.apply(hip, cam, 3, *[im.contiguous().float() for im in imgs], *vit_params)
         tok4 = tokens.view(3, B, hip.L, hip.out_dim)
         return tokens, tok4[:, :, 1:], tok4[:, :, 0]
 
     def _sim(self, tokens, B):
         hip = self.hip
+        hip.grad_mode = torch.is_grad_enabled()
         out, mask = SimFn.apply(hip, B, tokens, *[hip.flat.byname[n] for n in hip.sim_param_names])
         m = mask.unsqueeze(-1)
         self.SIM.token_selection.last_masks = {"RGB": m[0], "NI": m[1], "TI": m[2]}

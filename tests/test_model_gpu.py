@@ -126,3 +126,25 @@ def test_device_prefetcher_feeds_identical_batches(dev):
     for (gi, gv, gc, gw, _), (wi, wv, wc, ww, _) in zip(got, want):
         assert all(gi[m].is_cuda and torch.equal(gi[m].cpu(), wi[m]) for m in O.MODALITIES)
         assert torch.equal(gv.cpu(), wv) and torch.equal(gc.cpu(), wc)
+
+
+def test_inference_reuses_one_workspace(dev):
+    """Under torch.no_grad() the forward must take the (small) inference workspace and hand it back: a steady-state
+    step allocates nothing.  (ctx.needs_input_grad is True for parameters even in no-grad mode; the engine once took a
+    training workspace per step and zero-filled ~6 GB each time.)"""
+    ocfg = O.rgbnt201_config()
+    sd = O.init_state_dict(ocfg, seed=1234)
+    img, vid, cam = O.synthetic_batch(ocfg, 4, seed=5)
+    model = build(ocfg, sd, dev)
+    x = {k: v.to(dev) for k, v in img.items()}
+    calls = {"vit": [], "sim": []}
+    hip = model.hip
+    av, asim = hip._alloc_vit, hip._alloc_sim
+    hip._alloc_vit = lambda S, B, train: (calls["vit"].append(train), av(S, B, train))[1]
+    hip._alloc_sim = lambda B, train: (calls["sim"].append(train), asim(B, train))[1]
+    with torch.no_grad():
+        f0 = model(x, cam_label=cam.to(dev), training=False)
+        for _ in range(3):
+            f1 = model(x, cam_label=cam.to(dev), training=False)
+    assert calls == {"vit": [False], "sim": [False]}, calls
+    assert torch.equal(f0, f1)
