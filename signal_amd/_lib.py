@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsignal_hip.so")
+# SIGNAL_HIP_LIB: developer override for same-box A/B timing of two builds (tools/); the product always ships lib/libsignal_hip.so
+LIB_PATH = os.environ.get("SIGNAL_HIP_LIB") or os.path.join(_HERE, "lib", "libsignal_hip.so")
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 

@@ -161,7 +161,8 @@ extern "C" int sig_debug_read_stamps(unsigned long long* out, int nblocks) {
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, in an SGPR (LDS-DMA base goes to M0)
     // tile order: blocks of one XCD get a contiguous range of a BAND-major order (band = wb column tiles whose
     // weight rows, wb*128*K*2 B <= ~2.4 MB, stay resident in that XCD's 4 MB L2 while it sweeps the rows)
     const int tn = p.N >> 7, tm = gridDim.x / tn, wb = p.band;
@@ -183,9 +184,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     auto issue = [&](int kt, int stage) {
         char* sa = smem + stage * 32768 + wave * 4096;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(ag[j] + kt * 64, sa + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_untracked(ag[j] + kt * 64, sa + j * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(bg[j] + kt * 64, sa + 16384 + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_untracked(bg[j] + kt * 64, sa + 16384 + j * 1024);
     };
 
     // ---- fragment read offsets (bytes inside one operand tile) ----
@@ -222,21 +223,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
 #endif
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* s = smem + (kt & 1) * 32768;
+        // all 16 fragments of the K-step are requested up front (the DMA is issued untracked, so the compiler's waits
+        // are counted: the first MFMAs start when the ks = 0 fragments are in, the ks = 1 reads land under them)
+        bf16x8_t af[2][4], bf[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(s + aoff[ks] + i * 2048);
+            for (int i = 0; i < 4; ++i) af[ks][i] = *(const bf16x8_t*)(s + aoff[ks] + i * 2048);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *(const bf16x8_t*)(s + boff[ks] + j * 2048);
-            // operands swapped on purpose: D[row = n][col = m], so a lane owns 4 CONSECUTIVE n of one
-            // output row and the epilogue moves 8/16 B per lane
+            for (int j = 0; j < 4; ++j) bf[ks][j] = *(const bf16x8_t*)(s + boff[ks] + j * 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // operands swapped on purpose: D[row = n][col = m], so a lane owns 4 CONSECUTIVE n of one output row
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #ifdef SIG_GEMM_STAMPS
@@ -256,10 +262,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     // wave transposes its 64x64 f32 sub-tile through the now idle LDS (two 32-row passes, 68-float padded rows:
     // conflict-free b128 writes and reads) so a lane owns 8 CONSECUTIVE columns of one row: half the store
     // instructions, each a full 128-B (bf16) / 256-B (f32) row segment per 8 lanes.
-    __syncthreads();                                   // every wave is done reading operand fragments
-    float* stg = (float*)(smem + wave * (32 * 68 * 4));  // this wave's private staging area
     const int t8 = lane & 7, tr = lane >> 3;           // 8 lanes per row, 8 rows per instruction
     const int n = n0 + wn + t8 * 8;
+    // residual rows of this lane requested before the barrier and the staging, so their latency is off the store path
+    f32x4_t rres[2][4][2];
+    if (EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + wm + half * 32 + q * 8 + tr;
+                const float* r = p.res + (size_t)(m < p.M ? m : 0) * p.ldr + n;   // rows past M: any valid row, never used
+                rres[half][q][0] = *(const f32x4_t*)r;
+                rres[half][q][1] = *(const f32x4_t*)(r + 4);
+            }
+    }
+    __syncthreads();                                   // every wave is done reading operand fragments
+    float* stg = (float*)(smem + wave * (32 * 68 * 4));  // this wave's private staging area
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -292,10 +311,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
             }
             if (m >= p.M) continue;
             if (EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
-                const float* r = p.res + (size_t)m * p.ldr + n;
-                const f32x4_t r0 = *(const f32x4_t*)r, r1 = *(const f32x4_t*)(r + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                for (int e = 0; e < 4; ++e) { v[e] += rres[half][q][0][e]; v[4 + e] += rres[half][q][1][e]; }
             }
             if (EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) {
                 if (p.aux)   // pre-activation kept for backward
@@ -648,7 +665,8 @@ int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st) {
 // f32 atomics run at full rate (MI355X_MICROARCH 'Global float atomics').
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(SigGemmTN p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, in an SGPR (LDS-DMA base goes to M0)
     const int tj = p.J >> 7, ti = p.I >> 7;
     const int tiles = ti * tj;
     const int split = blockIdx.x / tiles, t = blockIdx.x - split * tiles;
@@ -672,9 +690,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(SigGemmTN p) {
     auto issue = [&](int kt, int stage) {
         char* sa = smem + stage * 32768 + wave * 4096;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(pg[j] + (size_t)kt * 64 * p.ldp, sa + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_untracked(pg[j] + (size_t)kt * 64 * p.ldp, sa + j * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(qg[j] + (size_t)kt * 64 * p.ldq, sa + 16384 + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_untracked(qg[j] + (size_t)kt * 64 * p.ldq, sa + 16384 + j * 1024);
     };
 
     // transposed-read addressing: lane = 16*G + 4*q + pp ; group G: column block 16*(G&1), k half h = G>>1
@@ -704,23 +722,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(SigGemmTN p) {
         __syncthreads();
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* s = smem + (kt & 1) * 32768;
+        // two 16-row slabs of fragments are requested ahead of the MFMAs that use them (the DMA is untracked, so the
+        // compiler's waits are counted and the second slab lands under the first slab's MFMAs)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {  // 16 rows of m per MFMA
-            bf16x8_t pf[2], qf[2];
+        for (int kp = 0; kp < 2; ++kp) {
+            bf16x8_t pf[2][2], qf[2][2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const bf16x4_t p0 = lds_tr16(s + poff[a] + ks * 4096);
-                const bf16x4_t p1 = lds_tr16(s + poff[a] + ks * 4096 + 1024);
-                const bf16x4_t q0 = lds_tr16(s + qoff[a] + ks * 4096);
-                const bf16x4_t q1 = lds_tr16(s + qoff[a] + ks * 4096 + 1024);
-                pf[a] = (bf16x8_t){p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-                qf[a] = (bf16x8_t){q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ks = kp * 2 + kk;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const bf16x4_t p0 = lds_tr16(s + poff[a] + ks * 4096);
+                    const bf16x4_t p1 = lds_tr16(s + poff[a] + ks * 4096 + 1024);
+                    const bf16x4_t q0 = lds_tr16(s + qoff[a] + ks * 4096);
+                    const bf16x4_t q1 = lds_tr16(s + qoff[a] + ks * 4096 + 1024);
+                    pf[kk][a] = (bf16x8_t){p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                    qf[kk][a] = (bf16x8_t){q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[kk][a], qf[kk][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -935,7 +963,10 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
     const int tiles = (p.I >> 7) * (p.J >> 7);
     // every split re-adds a whole 128x128 f32 tile with atomics (64 KB per workgroup, ~1.3 TB/s chip-wide), so use the
     // FEWEST row chunks that still fill the chip once: tiles * split <= 512 resident workgroups (2 per CU)
-    int split = p.split > 0 ? p.split : (512 / tiles > 0 ? 512 / tiles : 1);
+    // (measured, tools/tn_split_sweep.py: with few tiles the atomic flush dominates and ~one block per CU wins --
+    // 768x768: 14 chunks 71 us, 7 chunks 62 us; 768x512: 21 chunks 53 us, 8 chunks 43 us)
+    const int slots = tiles < 100 ? 256 : 512;
+    int split = p.split > 0 ? p.split : (slots / tiles > 0 ? slots / tiles : 1);
     if (split > ksteps) split = ksteps;
     const int per = sig_ceil_div(ksteps, split);
     split = sig_ceil_div(ksteps, per);

@@ -66,6 +66,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // Issued this way the DMA is invisible to that pass: the CALLER must `s_waitcnt vmcnt(0)` before anyone reads the
 // destination and before any compiler-tracked global load is consumed (its counted vmcnt would be off).
 __device__ __forceinline__ void glds16_untracked(const void* gsrc, void* lds_wave_base) {
+    // lds_wave_base must be wave-uniform IN AN SGPR (derive it from __builtin_amdgcn_readfirstlane(tid >> 6)): a
+    // readfirstlane here would cost a VALU->SALU hop per piece inside the K loop (+7 % on gemm_tn256_kernel)
     const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");   // m0 is reserved: not clobberable; kernels using this helper must not mix it with glds16()
 }

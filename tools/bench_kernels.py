@@ -36,6 +36,18 @@ for name, n, k, epi in [("qkv", 2304, 768, ops.BIAS_BF16), ("out_proj", 768, 768
     res["tn_" + name] = dict(ms=round(ms, 4), tflops=round(2 * M * n * k / ms / 1e9, 1))
     del a, w, out, dy, dw
 
+# dgrad shapes (plain bf16 output; the GELU' one reads the saved pre-activation)
+for name, n, k, epi in [("dgrad_qkv", 768, 2304, ops.BF16), ("dgrad_out_proj", 768, 768, ops.BF16), ("dgrad_c_fc", 768, 3072, ops.BF16),
+                        ("dgrad_c_proj", 3072, 768, ops.DGELU_BF16)]:
+    a = torch.randn(Mp, k, device=dev).to(torch.bfloat16)
+    w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+    out = torch.zeros(Mp, n, device=dev, dtype=torch.bfloat16)
+    aux = torch.randn(Mp, n, device=dev).to(torch.bfloat16) if epi == ops.DGELU_BF16 else None
+    cs = torch.zeros(n, device=dev)
+    ms = timeit(lambda: ops.gemm_nt(a, w, M, epi, out, aux=aux))
+    res["nt_" + name] = dict(ms=round(ms, 4), tflops=round(2 * M * n * k / ms / 1e9, 1))
+    del a, w, out
+
 S, L, H = 192, 129, 12
 qkv = torch.randn(Mp, 2304, device=dev).to(torch.bfloat16)
 o = torch.zeros(Mp, 768, device=dev, dtype=torch.bfloat16)
