@@ -395,18 +395,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
     const int tile_m = rr / wb, tile_n = bnd * wb + (rr - tile_m * wb);
     const int m0 = tile_m << 8, n0 = tile_n << 8;
 
-    // DMA pieces of this wave: A rows (wave*4+j)*8.., B rows likewise (256 rows = 32 pieces each, 8 waves x 4)
-    const bf16_t* ag[4];
-    const bf16_t* bg[4];
+    // DMA pieces of this wave: A rows (wave*4+j)*8.., B rows likewise (256 rows = 32 pieces each, 8 waves x 4).
+    // Source address = uniform tile base (+ kt*128 B, scalar) + a per-lane byte offset that never changes.
+    unsigned ao[4], bo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (wave * 4 + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        ag[j] = p.A + (size_t)(m0 + r) * p.lda + c * 8;
-        bg[j] = p.Bt + (size_t)(n0 + r) * p.ldb + c * 8;
+        ao[j] = (unsigned)(r * p.lda + c * 8) * 2u;
+        bo[j] = (unsigned)(r * p.ldb + c * 8) * 2u;
     }
-    auto dma_a = [&](int j, int kt, int stage) { glds16_untracked(ag[j] + kt * 64, smem + stage * STAGE + (wave * 4 + j) * 1024); };
-    auto dma_b = [&](int j, int kt, int stage) { glds16_untracked(bg[j] + kt * 64, smem + stage * STAGE + BM * 128 + (wave * 4 + j) * 1024); };
+    const bf16_t* abase = p.A + (size_t)m0 * p.lda;
+    const bf16_t* bbase = p.Bt + (size_t)n0 * p.ldb;
+    auto dma_a = [&](int j, int kt, int stage) { glds16_untracked_s(abase + kt * 64, ao[j], smem + stage * STAGE + (wave * 4 + j) * 1024); };
+    auto dma_b = [&](int j, int kt, int stage) { glds16_untracked_s(bbase + kt * 64, bo[j], smem + stage * STAGE + BM * 128 + (wave * 4 + j) * 1024); };
 
     const int fr = lane & 15, g = lane >> 4, sw = fr >> 1;
     const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
@@ -792,19 +794,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(SigGemmTN p) {
     const int nk = (mend - mbeg) >> 6;
     if (nk <= 0) return;
 
-    // DMA: a 1-KB piece = 2 rows x 512 B; 32 pieces per operand and stage, 4 + 4 per wave
-    const bf16_t* pg[4];
-    const bf16_t* qg[4];
+    // DMA: a 1-KB piece = 2 rows x 512 B; 32 pieces per operand and stage, 4 + 4 per wave.  Source address = uniform
+    // base (+ kt * 64 rows, scalar) + a constant per-lane byte offset.
+    unsigned po[4], qo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (wave * 4 + j) * 2 + (lane >> 5);
         const int c = (lane & 31) ^ ((r & 3) << 2);
-        pg[j] = p.P + (size_t)(mbeg + r) * p.ldp + i0 + c * 8;
-        qg[j] = p.Q + (size_t)(mbeg + r) * p.ldq + j0 + c * 8;
+        po[j] = (unsigned)(r * p.ldp + c * 8) * 2u;
+        qo[j] = (unsigned)(r * p.ldq + c * 8) * 2u;
     }
+    const bf16_t* pbase = p.P + (size_t)mbeg * p.ldp + i0;
+    const bf16_t* qbase = p.Q + (size_t)mbeg * p.ldq + j0;
     const size_t pstep = (size_t)64 * p.ldp, qstep = (size_t)64 * p.ldq;
-    auto dma_p = [&](int j, int kt, int stage) { glds16_untracked(pg[j] + kt * pstep, smem + stage * STAGE + (wave * 4 + j) * 1024); };
-    auto dma_q = [&](int j, int kt, int stage) { glds16_untracked(qg[j] + kt * qstep, smem + stage * STAGE + OPB + (wave * 4 + j) * 1024); };
+    auto dma_p = [&](int j, int kt, int stage) { glds16_untracked_s(pbase + kt * pstep, po[j], smem + stage * STAGE + (wave * 4 + j) * 1024); };
+    auto dma_q = [&](int j, int kt, int stage) { glds16_untracked_s(qbase + kt * qstep, qo[j], smem + stage * STAGE + OPB + (wave * 4 + j) * 1024); };
 
     // transposed-read addressing (see gemm_tn_kernel): lane = 16*G + 4*q + pp
     const int G = lane >> 4, h = G >> 1, tq = (lane >> 2) & 3, pp = lane & 3;

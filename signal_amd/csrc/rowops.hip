@@ -1,6 +1,8 @@
 // Row-wise, HBM-bound kernels around the contractions: LayerNorm fwd/bwd, weight packing (f32 -> bf16,
 // optional transpose), patch gather (im2col), token assembly (+CLS, camera, positional, ln_pre) and its
 // backward, column sums (bias gradients).  One wavefront per token row, 16-B accesses, shuffle reductions.
+#include <stdlib.h>
+
 #include "sig_common.h"
 #include "sig_kernels.h"
 
@@ -73,32 +75,46 @@ int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* be
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (register partials per wave, LDS across the 4 waves,
 // one atomic per column per workgroup).
 // ------------------------------------------------------------------------------------------------
-template <bool DY_BF16, int NV, bool SUMX>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+#ifndef LN_BWD_WPB
+#define LN_BWD_WPB 4    // waves per block of layernorm_bwd_kernel
+#endif
+template <bool DY_BF16, int NV, bool SUMX, int WPB>
+__global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dxf, bf16_t* __restrict__ dxb,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D,
                                                             float* __restrict__ dxsum) {
-    // NV = float4 per lane (D <= 256*NV): sized to the row so the per-lane accumulators stay small (more waves per SIMD)
-    __shared__ float red[SUMX ? 3 : 2][4][256 * NV];
+    // NV = float4 per lane (D <= 256*NV): sized to the row so the per-lane accumulators stay small (more waves per SIMD).
+    // Column sums (dgamma, dbeta, optional sum of dx): every wave parks its accumulators in its own LDS slice (plain
+    // b128 stores), the block adds the slices and issues one global atomic per column.  That flush runs at the
+    // memory-side atomic rate and the LDS slices cap residency, so the launcher uses FEW blocks with many rows each
+    // (in-model, D = 768, M = 24768: 2048 blocks 98 us, 512 blocks 71 us, 768 blocks 67 us; LDS float atomics instead of slices were
+    // slower at every block count, 16-wave blocks too).
+    __shared__ float red[SUMX ? 3 : 2][WPB][256 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 ag[NV], ab[NV], ax[SUMX ? NV : 1];
+    const bool sums = dgamma != nullptr || SUMX;
+    float4 ag[NV], ab[NV], ax[SUMX ? NV : 1], gm[NV];
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
         ag[it] = make_float4(0, 0, 0, 0);
         ab[it] = make_float4(0, 0, 0, 0);
         if (SUMX) ax[it] = make_float4(0, 0, 0, 0);
+        const int c = lane * 4 + it * 256;
+        gm[it] = c < D ? *(const float4*)(gamma + c) : make_float4(0, 0, 0, 0);
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * WPB + wave; row < M; row += gridDim.x * WPB) {
         const float mu = mean[row], rs = rstd[row];
-        float4 dyv[NV], xh[NV];
+        float4 dyv[NV], xh[NV], rv[NV];
         float s1 = 0.f, s2 = 0.f;
+        // every load of the row is requested before anything is consumed (the residual-stream gradient too: it used to
+        // be requested only after the two row reductions)
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int c = lane * 4 + it * 256;
             dyv[it] = make_float4(0, 0, 0, 0);
             xh[it] = make_float4(0, 0, 0, 0);
+            rv[it] = make_float4(0, 0, 0, 0);
             if (c < D) {
                 if (DY_BF16) {
                     const uint2 u = *(const uint2*)((const bf16_t*)dy_ + (size_t)row * D + c);
@@ -107,9 +123,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                 } else {
                     dyv[it] = *(const float4*)((const float*)dy_ + (size_t)row * D + c);
                 }
-                const float4 xv = *(const float4*)(x + (size_t)row * D + c);
-                const float4 g = *(const float4*)(gamma + c);
-                xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                xh[it] = *(const float4*)(x + (size_t)row * D + c);
+                if (dres) rv[it] = *(const float4*)(dres + (size_t)row * D + c);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int c = lane * 4 + it * 256;
+            if (c < D) {
+                const float4 g = gm[it];
+                xh[it] = make_float4((xh[it].x - mu) * rs, (xh[it].y - mu) * rs, (xh[it].z - mu) * rs, (xh[it].w - mu) * rs);
                 const float a0 = dyv[it].x * g.x, a1 = dyv[it].y * g.y, a2 = dyv[it].z * g.z, a3 = dyv[it].w * g.w;
                 s1 += a0 + a1 + a2 + a3;
                 s2 += a0 * xh[it].x + a1 * xh[it].y + a2 * xh[it].z + a3 * xh[it].w;
@@ -123,23 +146,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         for (int it = 0; it < NV; ++it) {
             const int c = lane * 4 + it * 256;
             if (c < D) {
-                const float4 g = *(const float4*)(gamma + c);
+                const float4 g = gm[it];
                 float4 o;
-                o.x = rs * (dyv[it].x * g.x - m1 - xh[it].x * m2);
-                o.y = rs * (dyv[it].y * g.y - m1 - xh[it].y * m2);
-                o.z = rs * (dyv[it].z * g.z - m1 - xh[it].z * m2);
-                o.w = rs * (dyv[it].w * g.w - m1 - xh[it].w * m2);
-                if (dres) {
-                    const float4 r = *(const float4*)(dres + (size_t)row * D + c);
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                }
+                o.x = rs * (dyv[it].x * g.x - m1 - xh[it].x * m2) + rv[it].x;
+                o.y = rs * (dyv[it].y * g.y - m1 - xh[it].y * m2) + rv[it].y;
+                o.z = rs * (dyv[it].z * g.z - m1 - xh[it].z * m2) + rv[it].z;
+                o.w = rs * (dyv[it].w * g.w - m1 - xh[it].w * m2) + rv[it].w;
                 if (dxf) *(float4*)(dxf + (size_t)row * D + c) = o;
                 if (dxb) *(uint2*)(dxb + (size_t)row * D + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
                 if (SUMX) { ax[it].x += o.x; ax[it].y += o.y; ax[it].z += o.z; ax[it].w += o.w; }
             }
         }
     }
-    if (!dgamma && !SUMX) return;
+    if (!sums) return;
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
         const int c = lane * 4 + it * 256;
@@ -148,12 +167,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         if (SUMX) *(float4*)&red[SUMX ? 2 : 0][wave][c] = ax[it];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) {
-        if (dgamma) {
-            atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-            atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    for (int c = threadIdx.x; c < D; c += 64 * WPB) {
+        float g = 0.f, bsum = 0.f, xs = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) {
+            g += red[0][w][c];
+            bsum += red[1][w][c];
+            if (SUMX) xs += red[SUMX ? 2 : 0][w][c];
         }
-        if (SUMX) atomicAdd(dxsum + c, red[SUMX ? 2 : 0][0][c] + red[SUMX ? 2 : 0][1][c] + red[SUMX ? 2 : 0][2][c] + red[SUMX ? 2 : 0][3][c]);
+        if (dgamma) {
+            atomicAdd(dgamma + c, g);
+            atomicAdd(dbeta + c, bsum);
+        }
+        if (SUMX) atomicAdd(dxsum + c, xs);
     }
 }
 
@@ -161,12 +187,13 @@ template <bool DY_BF16, int NV>
 static void launch_ln_bwd(int blocks, hipStream_t st, const void* dy, const float* x, const float* gamma, const float* mean,
                           const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma, float* dbeta, int M,
                           int D, float* dx_colsum) {
+    constexpr int WPB = LN_BWD_WPB;
     if (dx_colsum)
-        hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, true>), dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres, dx_f32,
-                           dx_bf16, dgamma, dbeta, M, D, dx_colsum);
+        hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, true, WPB>), dim3(blocks), dim3(64 * WPB), 0, st, dy, x, gamma, mean, rstd, dres,
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum);
     else
-        hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, false>), dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dres, dx_f32,
-                           dx_bf16, dgamma, dbeta, M, D, dx_colsum);
+        hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, false, WPB>), dim3(blocks), dim3(64 * WPB), 0, st, dy, x, gamma, mean, rstd, dres,
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum);
 }
 
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
@@ -175,8 +202,10 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     SIG_CHECK_ARG(M > 0 && D > 0 && (D & 3) == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D=%d unsupported", D);
     SIG_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SIG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
-    int blocks = sig_ceil_div(M, 4);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = sig_ceil_div(M, LN_BWD_WPB);
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("SIG_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 768; }
+    if (blocks > cap) blocks = cap;
     const int nv = (D + 255) / 256;
 #define SIG_LN(BF, NV_) launch_ln_bwd<BF, NV_>(blocks, st, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum)
     if (dy_is_bf16) {

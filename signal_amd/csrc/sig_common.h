@@ -71,6 +71,12 @@ __device__ __forceinline__ void glds16_untracked(const void* gsrc, void* lds_wav
     const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");   // m0 is reserved: not clobberable; kernels using this helper must not mix it with glds16()
 }
+// saddr form: source = 64-bit wave-uniform base (SGPR pair) + 32-bit per-lane byte offset.  The per-lane offsets of a
+// tile's pieces never change, the base moves by a scalar add per K-step: no vector instruction per piece.
+__device__ __forceinline__ void glds16_untracked_s(const void* uniform_base, unsigned lane_byte_off, void* lds_wave_base) {
+    const unsigned l = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_byte_off), "s"(uniform_base), "s"(l) : "memory");
+}
 // transposed LDS read: per 16-lane group a 4x16 block of 16-bit elements, delivered column-major
 __device__ __forceinline__ bf16x4_t lds_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)p);
