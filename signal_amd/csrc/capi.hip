@@ -40,7 +40,7 @@ int sig_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, int Mr, 
                 int split, void* stream) {
     SigGemmTN p;
     p.P = P; p.Q = Q; p.ldp = ldp; p.ldq = ldq; p.Mr = Mr; p.I = I; p.J = J; p.out = out; p.ldo = ldo;
-    p.split = split; p.m_chunk = 0;
+    p.split = split; p.m_chunk = 0; p.ws = nullptr;
     return sig_launch_gemm_tn(p, (hipStream_t)stream);
 }
 

@@ -72,6 +72,19 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
 #pragma unroll
     for (int j = 0; j < TN; ++j) csum[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bool save_u = GELU_FWD && p.aux != nullptr;
+    // GELU': the whole tile's saved pre-activations are requested before anything is consumed (TM*TN/2 16-B loads per
+    // lane, in the registers the operand fragments no longer need) -- inside the store loop their latency was exposed
+    // once per 16-row group
+    uint4 uq[GELU_BWD ? TM : 1][GELU_BWD ? TN / 2 : 1];
+    if (GELU_BWD) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + i * 16 + fr;
+#pragma unroll
+            for (int jp = 0; jp < TN / 2; ++jp)
+                uq[i][jp] = *(const uint4*)((const bf16_t*)p.aux + (size_t)(m < p.M ? m : 0) * p.ldaux + ns + jp * 32);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m_base + i * 16 + fr;
@@ -80,8 +93,7 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
         if (GELU_BWD) {
 #pragma unroll
             for (int jp = 0; jp < TN / 2; ++jp) {
-                uint4 q = make_uint4(0, 0, 0, 0);
-                if (live) q = *(const uint4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + ns + jp * 32);
+                uint4 q = uq[GELU_BWD ? i : 0][GELU_BWD ? jp : 0];
                 lane_swap16(q.x, q.z);
                 lane_swap16(q.y, q.w);
                 pu[2 * jp][0] = q.x; pu[2 * jp][1] = q.y;
@@ -914,18 +926,69 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(SigGemmTN p) {
     if (nk >= 2) step(nk - 2, T_{}, F_{});
     step(nk - 1, F_{}, F_{});
 
-    // D[row = I][col = J]: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): one register = two 128-B rows
+    // D[row = I][col = J]: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): one register = two 128-B rows.
+    // The block's 256x256 partial goes to its own workspace tile with plain stores (~6 TB/s); tn_reduce_kernel adds the
+    // row chunks into out.  Memory-side f32 atomics (1.3 TB/s) cost ~40 us of a ~130 us weight gradient here.
     const int col = lane & 31, rbase = 4 * (lane >> 5);
+    float* wt = p.ws ? p.ws + (size_t)id * 65536 : nullptr;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int ii = i0 + wi + a * 32 + (e & 3) + 8 * (e >> 2) + rbase;
-                const int jj = j0 + wj + b * 32 + col;
-                atomicAdd(p.out + (size_t)ii * p.ldo + jj, acc[a][b][e]);
+                const int il = wi + a * 32 + (e & 3) + 8 * (e >> 2) + rbase;
+                const int jl = wj + b * 32 + col;
+#ifdef SIG_TN_NOFLUSH   // diagnostic build (tools/tn_noflush.py): time the kernel without its flush
+                if (acc[a][b][e] == 1.2345e30f) p.out[(size_t)(i0 + il) * p.ldo + j0 + jl] = 0.f;
+#else
+                if (wt) wt[il * 256 + jl] = acc[a][b][e];
+                else atomicAdd(p.out + (size_t)(i0 + il) * p.ldo + j0 + jl, acc[a][b][e]);
+#endif
             }
+}
+
+// out[i][j] += sum over row chunks of the partial tiles written by gemm_tn256_kernel (unit = split * tiles + tile)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int I, int J, int ldo,
+                                                        int tiles, int split) {
+    const int tj = J >> 8;
+    const int q = blockIdx.x * 256 + threadIdx.x;           // one float4 of the output
+    const int per_row = J >> 2;
+    if (q >= I * per_row) return;
+    const int i = q / per_row, j = (q - i * per_row) << 2;
+    const int t = (i >> 8) * tj + (j >> 8);
+    const float* src = ws + (size_t)t * 65536 + (i & 255) * 256 + (j & 255);
+    f32x4_t acc = *(const f32x4_t*)src;
+    for (int s = 1; s < split; ++s) acc += *(const f32x4_t*)(src + (size_t)s * tiles * 65536);
+    float* o = out + (size_t)i * ldo + j;
+    if ((ldo & 3) == 0) {
+        *(f32x4_t*)o = *(const f32x4_t*)o + acc;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += acc[e];
+    }
+}
+
+// per-stream scratch for the partial tiles (<= 256 blocks x 256 KB); grown on demand, never freed
+static float* tn_workspace(hipStream_t st, size_t bytes) {
+    struct Ent { hipStream_t st; float* p; size_t bytes; };
+    static Ent ents[8];
+    static int n = 0;
+    for (int i = 0; i < n; ++i)
+        if (ents[i].st == st) {
+            if (ents[i].bytes < bytes) {
+                (void)hipStreamSynchronize(st);
+                (void)hipFree(ents[i].p);
+                if (hipMalloc((void**)&ents[i].p, bytes) != hipSuccess) { ents[i].p = nullptr; ents[i].bytes = 0; return nullptr; }
+                ents[i].bytes = bytes;
+            }
+            return ents[i].p;
+        }
+    if (n == 8) return nullptr;   // more streams than slots: fall back to atomics
+    float* ptr = nullptr;
+    if (hipMalloc((void**)&ptr, bytes) != hipSuccess) return nullptr;
+    ents[n++] = {st, ptr, bytes};
+    return ptr;
 }
 
 int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
@@ -960,8 +1023,16 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
         const int per = sig_ceil_div(ksteps, split);
         split = sig_ceil_div(ksteps, per);
         p.m_chunk = per * 64;
+        static int use_ws = -1;
+        if (use_ws < 0) { const char* e = getenv("SIG_GEMM_TN_ATOMICS"); use_ws = e && atoi(e) ? 0 : 1; }
+        p.ws = use_ws ? tn_workspace(st, (size_t)tiles * split * 65536 * sizeof(float)) : nullptr;
         hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * split), dim3(512), 131072, st, p);
         SIG_CHECK_LAUNCH("gemm_tn256");
+        if (p.ws) {
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3(sig_ceil_div(p.I * (p.J >> 2), 256)), dim3(256), 0, st, p.ws, p.out, p.I, p.J, p.ldo,
+                               tiles, split);
+            SIG_CHECK_LAUNCH("tn_reduce");
+        }
         return 0;
     }
     const int tiles = (p.I >> 7) * (p.J >> 7);

@@ -44,6 +44,7 @@ struct SigGemmTN {
     int ldo;
     int split;        // 0 = choose
     int m_chunk;      // filled by the launcher
+    float* ws;        // filled by the launcher: per-block partial tiles (256x256 kernel), nullptr = atomics into out
 };
 int sig_launch_gemm_tn(const SigGemmTN& p, hipStream_t st);
 

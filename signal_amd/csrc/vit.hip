@@ -35,7 +35,7 @@ static SigGemmNT with_colsum(SigGemmNT p, float* colsum) {
 static SigGemmTN tn(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int Mr, int I, int J, float* out, int ldo) {
     SigGemmTN p;
     p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.Mr = Mr; p.I = I; p.J = J; p.out = out; p.ldo = ldo;
-    p.split = 0; p.m_chunk = 0;
+    p.split = 0; p.m_chunk = 0; p.ws = nullptr;
     return p;
 }
 
