@@ -35,7 +35,10 @@ def padded(t, ops):
     return out
 
 
-GEMM_SHAPES = [(774, 384, 128), (1000, 768, 3072), (4128, 2304, 768), (129, 128, 64), (2000, 512, 192)]
+# the last two select the 256x256 phase-pipelined kernel (>= 512 tiles; K = 128 is its shortest legal loop, the last row
+# tile is partial: 24768 = 96 * 256 + 192)
+GEMM_SHAPES = [(774, 384, 128), (1000, 768, 3072), (4128, 2304, 768), (129, 128, 64), (2000, 512, 192), (24768, 1536, 128),
+               (24768, 1536, 192)]
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -83,6 +86,20 @@ def test_gemm_nt_epilogues(dev, m, n, k):
     ops.gemm_nt(ap, w, m, ops.DGELU_BF16, ob, aux=padded(uu, ops))
     s = torch.sigmoid(1.702 * uu.float())
     assert rel_err(ob[:m].float(), ref * (s * (1 + 1.702 * uu.float() * (1 - s)))) < 4e-3
+    assert not bool(ob[m:].abs().any()), "pad rows must stay untouched"
+
+    # erf-GELU pair (SIM's FFN) and the bias-free residual epilogue
+    ops.gemm_nt(ap, w, m, ops.BIAS_GELUERF_BF16, ob, bias=bias, aux=u)
+    assert rel_err(u[:m].float(), pre) < 3e-3
+    assert rel_err(ob[:m].float(), torch.nn.functional.gelu(pre)) < 4e-3
+    ops.gemm_nt(ap, w, m, ops.DGELUERF_BF16, ob, aux=padded(uu, ops))
+    uf = uu.float()
+    dg = 0.5 * (1 + torch.erf(uf * 0.7071067811865476)) + uf * torch.exp(-0.5 * uf * uf) * 0.3989422804014327
+    assert rel_err(ob[:m].float(), ref * dg) < 4e-3
+    out.zero_()
+    ops.gemm_nt(ap, w, m, ops.RES_F32, out, res=res)
+    assert rel_err(out[:m], ref + res) < 2e-6
+    assert not bool(out[m:].abs().any())
 
 
 @pytest.mark.parametrize("mr,i,j", [(128, 128, 128), (896, 384, 128), (4160, 768, 256), (24832, 256, 128), (8192, 1536, 768),
