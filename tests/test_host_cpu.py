@@ -246,3 +246,49 @@ def test_synthetic_triplet_source_shape():
     img, vid, cam, view, _ = batches[0]
     assert set(img) == {"RGB", "NI", "TI"} and img["NI"].shape == (16, 3, 256, 128) and img["NI"].dtype == torch.float32
     assert vid.tolist() == [i // 4 for i in range(16)] and int(cam.max()) < 4
+
+
+# ---------------------------------------------------------------------------------------------------------
+# learning-rate schedules against G8 (generated by the reference's own solver/ modules, tests/golden/make_golden_sched.py)
+# ---------------------------------------------------------------------------------------------------------
+def _three_groups(base):
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(3)]
+    return torch.optim.Adam([{"params": [ps[0]], "lr": base}, {"params": [ps[1]], "lr": 2 * base}, {"params": [ps[2]], "lr": 5e-6}])
+
+
+@pytest.mark.parametrize("tag", ["rgbnt201", "rgbnt100", "nowarm"])
+def test_noisy_cosine_schedule_matches_reference(golden, tag):
+    import types
+    from signal_amd.solver import create_scheduler
+    g = golden("g8_lr_schedule")
+    base, warm, epochs = g[f"{tag}_cfg"]
+    cfg = types.SimpleNamespace(SOLVER=types.SimpleNamespace(MAX_EPOCHS=int(epochs), BASE_LR=float(base), WARMUP_ITERS=int(warm)))
+    opt = _three_groups(float(base))
+    sch = create_scheduler(cfg, opt)
+    rows, clean = [[gr["lr"] for gr in opt.param_groups]], []
+    for epoch in range(1, int(epochs) + 4):
+        sch.step(epoch)
+        rows.append([gr["lr"] for gr in opt.param_groups])
+        clean.append(sch._get_lr(epoch))
+    np.testing.assert_allclose(np.array(rows), g[f"{tag}_after_step"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(np.array(clean), g[f"{tag}_noise_free"], rtol=1e-12, atol=0)
+    if warm:   # the warm-up quirk: the 5e-6 backbone group starts at 0.1 * BASE_LR, far above its base value
+        assert rows[0][2] == pytest.approx(0.1 * base) and rows[0][2] > 5e-6
+    assert clean[-1] == [pytest.approx(0.001 * base)] * 3          # past MAX_EPOCHS every group sits on the floor
+
+
+@pytest.mark.parametrize("tag,wit", [("msvr310", 0), ("msvr310_warm10", 10)])
+def test_warmup_multistep_matches_reference(golden, tag, wit):
+    from signal_amd.solver import WarmupMultiStepLR
+    g = golden("g8_lr_schedule")
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+    opt = torch.optim.Adam([{"params": [ps[0]], "lr": 5e-6}, {"params": [ps[1]], "lr": 5e-4}])
+    sch = WarmupMultiStepLR(opt, [20, 40], 0.1, 0.01, wit, "linear")
+    rows = [[gr["lr"] for gr in opt.param_groups]]
+    for _ in range(50):
+        opt.step()
+        sch.step()
+        rows.append([gr["lr"] for gr in opt.param_groups])
+    np.testing.assert_allclose(np.array(rows), g[f"{tag}_lr"], rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        WarmupMultiStepLR(opt, [40, 20])
