@@ -11,6 +11,7 @@
 // activations make one HBM round trip per contraction.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "sig_common.h"
@@ -969,13 +970,17 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
-// per-stream scratch for the partial tiles (<= 256 blocks x 256 KB); grown on demand, never freed
+// per-(device, stream) scratch for the partial tiles (<= 256 blocks x 256 KB); grown on demand, never freed
 static float* tn_workspace(hipStream_t st, size_t bytes) {
-    struct Ent { hipStream_t st; float* p; size_t bytes; };
-    static Ent ents[8];
+    struct Ent { int dev; hipStream_t st; float* p; size_t bytes; };
+    static Ent ents[16];
     static int n = 0;
+    static std::mutex mu;   // forward runs on the caller's thread, backward on autograd's
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     for (int i = 0; i < n; ++i)
-        if (ents[i].st == st) {
+        if (ents[i].st == st && ents[i].dev == dev) {
             if (ents[i].bytes < bytes) {
                 (void)hipStreamSynchronize(st);
                 (void)hipFree(ents[i].p);
@@ -984,10 +989,10 @@ static float* tn_workspace(hipStream_t st, size_t bytes) {
             }
             return ents[i].p;
         }
-    if (n == 8) return nullptr;   // more streams than slots: fall back to atomics
+    if (n == 16) return nullptr;   // more (device, stream) pairs than slots: the caller falls back to atomics
     float* ptr = nullptr;
     if (hipMalloc((void**)&ptr, bytes) != hipSuccess) return nullptr;
-    ents[n++] = {st, ptr, bytes};
+    ents[n++] = {dev, st, ptr, bytes};
     return ptr;
 }
 
