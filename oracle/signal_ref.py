@@ -487,6 +487,17 @@ def triplet_soft(feat: Tensor, labels: Tensor) -> Tensor:
     return F.softplus(-(d_an - d_ap)).mean()
 
 
+def triplet_margin(feat: Tensor, labels: Tensor, margin: float) -> Tensor:
+    """TripletLoss(margin): nn.MarginRankingLoss(margin)(d_an, d_ap, 1) = mean(relu(d_ap - d_an + margin)) on the same
+    batch-hard distances (triplet_loss.py:107-135, the MODEL.NO_MARGIN=False branch of make_loss.py:66-72)."""
+    sq = (feat * feat).sum(1, keepdim=True)
+    dist = (sq + sq.t() - 2.0 * feat @ feat.t()).clamp(min=1e-12).sqrt()
+    same = labels[:, None] == labels[None, :]
+    d_ap = torch.where(same, dist, torch.full_like(dist, -float("inf"))).max(1).values
+    d_an = torch.where(same, torch.full_like(dist, float("inf")), dist).min(1).values
+    return F.relu(d_ap - d_an + margin).mean()
+
+
 def reid_loss(cfg: RefConfig, score: Tensor, feat: Tensor, target: Tensor) -> Tensor:
     """loss_func of make_loss (make_loss.py:109-150), label-smooth on, soft triplet."""
     return (cfg.id_loss_weight * id_loss(score, target, cfg.label_smooth_eps)

@@ -95,4 +95,6 @@ class ReidLossFn(torch.autograd.Function):
 
 
 def reid_loss(score, feat, target, eps, w_id, w_tri, margin):
+    if w_tri != 0.0:   # the reference fails on a one-identity batch (triplet_loss.py:79-84); device-side check, no host sync
+        torch._assert_async((target != target.reshape(-1)[0]).any(), "batch-hard mining needs at least two identities in the batch")
     return ReidLossFn.apply(score, feat, target, eps, w_id, w_tri, -1.0 if margin is None else float(margin))

@@ -101,28 +101,34 @@ def test_config_node():
         c.MODEL.TOPK = 1
 
 
-def test_reid_loss_matches_oracle_and_reference_fixture(golden):
+def test_loss_factory_refuses_host_tensors_and_assembles_like_the_processor():
+    """The ReID loss itself runs in HIP only (parity vs G6: tests/test_train_gpu.py; oracle vs G6: test_oracle_golden);
+    here: the factory contract, the loud failure on host tensors, and the loss assembly of processor.py:244-256."""
+    from signal_amd._lib import SignalHipError
     from signal_amd.config import get_cfg_defaults
     from signal_amd.layers.make_loss import make_loss, total_loss
-    g = golden("g6_reid")
-    gen = O._rng(int(g["seed"]))
-    score = O.randn(gen, 16, 171, std=2.0).requires_grad_(True)
-    feat = O.randn(gen, 16, 1536, std=1.0).requires_grad_(True)
-    target = torch.arange(16) // 4 + 7
     cfg = get_cfg_defaults()
     cfg.merge_from_file(os.path.join(ROOT, "configs", "RGBNT201", "Signal.yml"))
     loss_fn, center = make_loss(cfg, 171)
-    loss = loss_fn(score=score, feat=feat, target=target, target_cam=None)
-    loss.backward()
-    np.testing.assert_allclose(loss.item(), 0.25 * float(g["id_loss"]) + float(g["tri_loss"]), rtol=1e-5)
-    np.testing.assert_allclose(score.grad[:2].numpy(), g["dscore_rows"], rtol=1e-4, atol=1e-8)
-    np.testing.assert_allclose(feat.grad.norm(dim=1).numpy(), g["dfeat_norm"], rtol=1e-4)
-    # loss assembly of processor.py:244-256 (sign 3, GAM + LAM)
+    assert center is None
+    score, feat, target = torch.randn(16, 171), torch.randn(16, 1536), torch.arange(16) // 4
+    with pytest.raises(SignalHipError, match="no CPU path"):
+        loss_fn(score=score, feat=feat, target=target, target_cam=None)
+    with pytest.raises(NotImplementedError):
+        loss_fn(score=[score, score], feat=[feat, feat], target=target, target_cam=None)
+    # assembly (sign 3, GAM + LAM) with a stand-in pair loss
+    pair = lambda score, feat, target, target_cam: score.sum() * 0 + 1.5   # noqa: E731
     out = (3, score, feat, score, feat, torch.tensor(2.0), torch.tensor(3.0))
-    tot = total_loss(cfg, out, loss_fn, target, None, "together_CLS_Patch")
-    np.testing.assert_allclose(tot.item(), 2 * loss.item() + 0.2 * 2.0 + 0.2 * 3.0, rtol=1e-6)
+    tot = total_loss(cfg, out, pair, target, None, "together_CLS_Patch")
+    np.testing.assert_allclose(float(tot), 2 * 1.5 + 0.2 * 2.0 + 0.2 * 3.0, rtol=1e-6)
+    tot = total_loss(cfg, out[:-1], pair, target, None, "CLS")
+    np.testing.assert_allclose(float(tot), 2 * 1.5 + 0.2 * 2.0, rtol=1e-6)
+    tot = total_loss(cfg, (2, score, feat, score, feat), pair, target, None, "CLS")
+    np.testing.assert_allclose(float(tot), 3.0, rtol=1e-6)
+    cfg2 = get_cfg_defaults()
+    cfg2.MODEL.METRIC_LOSS_TYPE = "center"
     with pytest.raises(ValueError):
-        loss_fn(score=score, feat=feat, target=torch.zeros(16, dtype=torch.long), target_cam=None)
+        make_loss(cfg2, 171)
 
 
 def test_optimizer_rules_follow_the_reference():

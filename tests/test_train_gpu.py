@@ -217,16 +217,24 @@ def test_reid_loss_hip_vs_reference_fixture(dev, golden):
     np.testing.assert_allclose(loss.item(), 0.25 * float(g["id_loss"]) + float(g["tri_loss"]), rtol=1e-5)
     np.testing.assert_allclose(score.grad[:2].cpu().numpy() / 2, g["dscore_rows"], rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(feat.grad.norm(dim=1).cpu().numpy() / 2, g["dfeat_norm"], rtol=1e-4)
-    # margin form against the PyTorch host implementation
-    from signal_amd.layers.make_loss import TripletLoss
+    # margin form (MODEL.NO_MARGIN = False) against the oracle
     f2 = feat.detach().clone().requires_grad_(True)
     l2 = reid_loss(score.detach(), f2, target, 0.0, 0.0, 1.0, 0.3)
     l2.backward()
     f3 = feat.detach().cpu().clone().requires_grad_(True)
-    l3 = TripletLoss(0.3)(f3, target.cpu())[0]
+    l3 = O.triplet_margin(f3, target.cpu(), 0.3)
     l3.backward()
     np.testing.assert_allclose(l2.item(), l3.item(), rtol=1e-5)
     assert rel_err(f2.grad, f3.grad) < 1e-4
+    # plain cross entropy (DATALOADER.SAMPLER = 'softmax'): eps 0, no triplet term
+    s2 = score.detach().clone().requires_grad_(True)
+    l4 = reid_loss(s2, feat.detach(), target, 0.0, 1.0, 0.0, None)
+    l4.backward()
+    s3 = score.detach().cpu().clone().requires_grad_(True)
+    l5 = torch.nn.functional.cross_entropy(s3, target.cpu())
+    l5.backward()
+    np.testing.assert_allclose(l4.item(), l5.item(), rtol=1e-5)
+    assert rel_err(s2.grad, s3.grad) < 1e-4
 
 
 @pytest.mark.parametrize("B,F,C", [(8, 1536, 171), (64, 512, 50)])
