@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void lam_tail_bwd_kernel(const float* __restri
                                                            const float* __restrict__ samp_all, size_t nsamp,
                                                            const float* __restrict__ dloss, bf16_t* __restrict__ da1pre,
                                                            float* __restrict__ dwd, float* __restrict__ dbd, float* __restrict__ dw4,
-                                                           float* __restrict__ dtokens) {
+                                                           float* __restrict__ dtokens, float* __restrict__ part) {
     __shared__ float red[8][16];
     __shared__ float dofs[8];
     const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
@@ -420,10 +420,31 @@ __global__ __launch_bounds__(512) void lam_tail_bwd_kernel(const float* __restri
                 da1pre[row * AL_D + c] = f2bf(da1 * gelu_erf_grad(bf2f(a1pre[row * AL_D + c])));
             }
     }
-    atomicAdd(dw4 + c, dw4c);
-    atomicAdd(dbd + c, dbdc);
+    // Parameter gradients: one partial row per sample, [B][18 * 512] = (dwd[512*16] | dbd[512] | dw4[512]), summed by
+    // lam_tail_reduce_kernel.  Atomics straight into dwd/dbd/dw4 had all 64 sample blocks hit the same 9216 addresses
+    // (the 14x-slower contention case of MI355X_MICROARCH 'Global float atomics'): 106 us per modality.
+    if (part) {
+        float* pr = part + (size_t)b * (18 * AL_D);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) atomicAdd(dwd + c * 16 + k, dwdc[k]);
+        for (int k = 0; k < 16; ++k) pr[c * 16 + k] = dwdc[k];
+        pr[16 * AL_D + c] = dbdc;
+        pr[17 * AL_D + c] = dw4c;
+    } else {
+        atomicAdd(dw4 + c, dw4c);
+        atomicAdd(dbd + c, dbdc);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) atomicAdd(dwd + c * 16 + k, dwdc[k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void lam_tail_reduce_kernel(const float* __restrict__ part, int B, float* __restrict__ dwd,
+                                                              float* __restrict__ dbd, float* __restrict__ dw4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 18 * AL_D) return;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += part[(size_t)b * (18 * AL_D) + i];
+    float* dst = i < 16 * AL_D ? dwd + i : (i < 17 * AL_D ? dbd + (i - 16 * AL_D) : dw4 + (i - 17 * AL_D));
+    *dst += a;
 }
 
 int sig_launch_lam_gather(const float* tokens, int B, int L, bf16_t* xb, size_t xstride, hipStream_t st) {
@@ -465,11 +486,16 @@ int sig_launch_lam_loss(const float* samp, size_t n, float* loss, hipStream_t st
 int sig_launch_lam_tail_bwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre,
                             const float* wd, const float* w4, const float* a2pre, const float* offs, const float* samp_all,
                             size_t nsamp, const float* dloss, bf16_t* da1pre, float* dwd, float* dbd, float* dw4, float* dtokens,
-                            hipStream_t st) {
+                            hipStream_t st, float* partials) {
     LamGeom g;
     if (int rc = lam_geom(h, w, &g)) return rc;
+    // partials: caller scratch of >= B * 18 * 512 floats (nullptr -> contended atomics straight into the gradients)
     hipLaunchKernelGGL(lam_tail_bwd_kernel, dim3(B), dim3(512), 0, st, tokens, m, L, B, g, a1, a1pre, wd, w4, a2pre, offs, samp_all,
-                       nsamp, dloss, da1pre, dwd, dbd, dw4, dtokens);
+                       nsamp, dloss, da1pre, dwd, dbd, dw4, dtokens, partials);
     SIG_CHECK_LAUNCH("lam_tail_bwd");
+    if (partials) {
+        hipLaunchKernelGGL(lam_tail_reduce_kernel, dim3(sig_ceil_div(18 * AL_D, 256)), dim3(256), 0, st, partials, B, dwd, dbd, dw4);
+        SIG_CHECK_LAUNCH("lam_tail_reduce");
+    }
     return 0;
 }

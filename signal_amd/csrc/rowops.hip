@@ -451,34 +451,48 @@ int sig_launch_embed_assemble(const float* tok, const float* cls_emb, const floa
 }
 
 // backward of the assembly (given d pre-LN tokens): dtok (f32 and/or bf16, [S*Lp, D]), dpos[l] = sum_s,
-// dcls = sum_s d[s,0], dcv[cam] += sie * d[s,0].  One workgroup column-slab per token position.
+// dcls = sum_s d[s,0], dcv[cam] += sie * d[s,0].  Block = (token position, chunk of sequences, 1024-column slab); a lane
+// owns 4 consecutive columns (16-B loads/stores) and walks its chunk of sequences; one atomic per column and chunk.
+// (One block per position walking all 192 sequences with 4-B accesses ran at ~1 TB/s: 114 us.)
+#define EMB_BWD_CHUNKS 8
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dpre, float* __restrict__ dtokf, bf16_t* __restrict__ dtokb,
                                                         float* __restrict__ dcls, float* __restrict__ dpos, float* __restrict__ dcv,
                                                         const int64_t* __restrict__ cam, float sie, int S, int B, int L, int D) {
     const int l = blockIdx.x;
-    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
     if (c >= D) return;
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float v = dpre[((size_t)s * L + l) * D + c];
+    const int per = (S + EMB_BWD_CHUNKS - 1) / EMB_BWD_CHUNKS;
+    const int s0 = blockIdx.y * per, s1 = s0 + per < S ? s0 + per : S;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < s1; ++s) {
+        const f32x4_t v = *(const f32x4_t*)(dpre + ((size_t)s * L + l) * D + c);
         acc += v;
         if (l == 0) {
-            if (dcv) atomicAdd(dcv + (size_t)cam[s % B] * D + c, sie * v);
+            if (dcv) {
+                float* dst = dcv + (size_t)cam[s % B] * D + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + e, sie * v[e]);
+            }
         } else {
             const size_t o = ((size_t)s * (L - 1) + (l - 1)) * D + c;
-            if (dtokf) dtokf[o] = v;
-            if (dtokb) dtokb[o] = f2bf(v);
+            if (dtokf) *(f32x4_t*)(dtokf + o) = v;
+            if (dtokb) *(uint2*)(dtokb + o) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
     }
-    atomicAdd(dpos + (size_t)l * D + c, acc);
-    if (l == 0) atomicAdd(dcls + c, acc);
+    if (s1 <= s0) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        atomicAdd(dpos + (size_t)l * D + c + e, acc[e]);
+        if (l == 0) atomicAdd(dcls + c + e, acc[e]);
+    }
 }
 int sig_launch_embed_bwd(const float* dx_pre, float* dtok_f32, bf16_t* dtok_bf16, float* dcls, float* dpos,
                          float* dcv, const int64_t* cam, float sie_coe, int S, int B, int L, int D, hipStream_t st) {
     SIG_CHECK_ARG(dx_pre && dcls && dpos && (dtok_f32 || dtok_bf16), "embed_bwd: null pointer");
     SIG_CHECK_ARG((dcv == nullptr) || cam, "embed_bwd: cam labels missing");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(L, sig_ceil_div(D, 256)), dim3(256), 0, st, dx_pre, dtok_f32, dtok_bf16, dcls,
-                       dpos, dcv, cam, sie_coe, S, B, L, D);
+    SIG_CHECK_ARG((D & 3) == 0, "embed_bwd: D=%d must be a multiple of 4", D);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(L, EMB_BWD_CHUNKS, sig_ceil_div(D, 1024)), dim3(256), 0, st, dx_pre, dtok_f32, dtok_bf16,
+                       dcls, dpos, dcv, cam, sie_coe, S, B, L, D);
     SIG_CHECK_LAUNCH("embed_bwd");
     return 0;
 }

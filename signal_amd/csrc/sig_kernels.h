@@ -97,7 +97,7 @@ int sig_launch_lam_loss(const float* samp, size_t n, float* loss, hipStream_t st
 int sig_launch_lam_tail_bwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre,
                             const float* wd, const float* w4, const float* a2pre, const float* offs, const float* samp_all,
                             size_t nsamp, const float* dloss, bf16_t* da1pre, float* dwd, float* dbd, float* dw4, float* dtokens,
-                            hipStream_t st);
+                            hipStream_t st, float* partials = nullptr);
 
 // ---- optimizer (optim.hip) ------------------------------------------------------------------------------
 int sig_launch_adam(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, const int* seg_end, const float* seg_lr,

@@ -274,7 +274,8 @@ int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, const SigDasPar
         SIG_CHECK_ARG(p->wt_q && p->wt_0, "lam_bwd: transposed weights missing");
         const size_t o = (size_t)m * Rp * d;
         RUN(sig_launch_lam_tail_bwd(tokens, m, B, L, h, w, a->a1 + o, a->a1pre + o, p->wd, p->w4, a->a2pre + (size_t)m * nsamp,
-                                    a->offs + (size_t)m * B * P * 3, a->samp, nsamp, dloss, s->da1pre, g->wd, g->bd, g->w4, dtokens, st));
+                                    a->offs + (size_t)m * B * P * 3, a->samp, nsamp, dloss, s->da1pre, g->wd, g->bd, g->w4, dtokens, st,
+                                    (size_t)B * 18 * d <= (size_t)Rp * d ? s->dx : nullptr));   // dx is free until the proj_q dgrad below
         // conv_offset.0
         RUN(sig_launch_gemm_nt(nt(s->da1pre, d, p->wt_0, d, R, d, d, s->dq, d), SIG_EPI_BF16, st));
         RUN(sig_launch_gemm_tn(tn(s->da1pre, d, a->q + o, d, Rp, d, d, g->w_0, d), st));
