@@ -148,3 +148,29 @@ def test_inference_reuses_one_workspace(dev):
             f1 = model(x, cam_label=cam.to(dev), training=False)
     assert calls == {"vit": [False], "sim": [False]}, calls
     assert torch.equal(f0, f1)
+
+
+@pytest.mark.parametrize("B,tag", [(1, "rgbnt201"), (7, "rgbnt201"), (3, "rgbnt100")])
+def test_inference_odd_batches_vs_oracle(dev, B, tag):
+    """Ragged sizes: one sample (M = 387 token rows: a single partial 128-row tile, SIM with B = 1) and batches that are
+    not multiples of anything; the same model instance is then reused at another batch size (workspace pools are keyed
+    by shape)."""
+    ocfg = O.rgbnt201_config() if tag == "rgbnt201" else O.rgbnt100_config()
+    sd = O.init_state_dict(ocfg, seed=77)
+    model = build(ocfg, sd, dev)
+    for b in (B, B + 1):
+        img, vid, cam = O.synthetic_batch(ocfg, b, seed=100 + b)
+        with torch.no_grad():
+            ref = O.signal_forward_infer(sd, ocfg, img, cam)
+            feat = model({k: v.to(dev) for k, v in img.items()}, cam_label=cam.to(dev), training=False)
+        assert feat.shape == ref.shape == (b, 3072)
+        assert torch.isfinite(feat).all()
+        assert rel_err(feat[:, :1536], ref[:, :1536]) < 1e-2
+        # SIM features: compare the samples whose selection masks agree with the fp32 oracle's (see the test above)
+        patches, cls = O.backbone3(sd, ocfg, img, cam)
+        ref_mask, _ = O.sim_select(sd, patches, cls, ocfg.topk)
+        hip_mask = torch.stack([model.SIM.token_selection.last_masks[m][..., 0] for m in O.MODALITIES]).bool().cpu()
+        same = (hip_mask == ref_mask).all(dim=2).all(dim=0)
+        assert (hip_mask == ref_mask).float().mean().item() > 0.97
+        if same.any():
+            assert rel_err(feat[same][:, 1536:], ref[same][:, 1536:]) < 2e-2
