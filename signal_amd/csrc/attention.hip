@@ -55,7 +55,9 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8_t*)(base + (size_t)qc * D3 + ks * 32 + g * 8);
 
-        // S^T tiles: lane holds keys kt*16 + 4g + reg of query fr
+        // S^T tiles: lane holds keys kt*16 + 4g + reg of query fr.  Scores stay RAW (unscaled): the 1/8 is folded into the
+        // exponent below; only the tail key tile needs masking (the kernel is instruction-issue bound: ~440 instructions
+        // per query tile before this diet).
         f32x4_t sc[ATT_NT + 1];
         float mx = -INFINITY;
 #pragma unroll
@@ -67,23 +69,27 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
                     const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(kt * 16 + fr, (ks << 2) | g));
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);
                 }
-            }
+                if (kt * 16 + 16 > L) {   // uniform: the tile that straddles L
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = kt * 16 + 4 * g + e;
-                a[e] = key < L ? a[e] * scale : -INFINITY;
-                mx = fmaxf(mx, a[e]);
+                    for (int e = 0; e < 4; ++e)
+                        if (kt * 16 + 4 * g + e >= L) a[e] = -INFINITY;
+                }
+            } else {
+                a = (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             }
+            mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
             sc[kt] = a;
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // p = exp(scale * (s - mx)) = 2^(s*c - mx*c), c = scale * log2(e): one FMA + one v_exp per element
+        const float c2 = scale * 1.4426950408889634f, mc = -mx * c2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < ATT_NT; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pv = __expf(sc[kt][e] - mx);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][e], c2, mc));
                 sc[kt][e] = pv;
                 sum += pv;
             }
@@ -99,9 +105,10 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int kk = 0; kk < (ATT_NT + 1) / 2; ++kk) {
             if (kk * 2 >= NT) break;
             const f32x4_t p0 = sc[2 * kk], p1 = sc[2 * kk + 1];
-            bf16x8_t pf;
-            pf[0] = (short)f2bf(p0[0]); pf[1] = (short)f2bf(p0[1]); pf[2] = (short)f2bf(p0[2]); pf[3] = (short)f2bf(p0[3]);
-            pf[4] = (short)f2bf(p1[0]); pf[5] = (short)f2bf(p1[1]); pf[6] = (short)f2bf(p1[2]); pf[7] = (short)f2bf(p1[3]);
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+            pk.w[0] = pack2bf(p0[0], p0[1]); pk.w[1] = pack2bf(p0[2], p0[3]);
+            pk.w[2] = pack2bf(p1[0], p1[1]); pk.w[3] = pack2bf(p1[2], p1[3]);
+            const bf16x8_t pf = pk.v;
             const int r0 = 32 * kk + 4 * g + tq;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -112,13 +119,26 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
             }
         }
-        if (q < L) {
+        // lane (fr, g) holds head columns dt*16 + 4g .. +3 of query fr: exchange lane pairs g / g^1 (v_permlane16_swap, as
+        // in the GEMM epilogue) so that a lane owns 8 consecutive columns -> two 16-B stores instead of four 8-B ones
+        {
             const float inv = 1.0f / sum;
-            bf16_t* orow = out + ((size_t)s * L + q) * Dm + h * 64 + 4 * g;
+            uint32_t w[4][2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *(uint2*)(orow + dt * 16) = make_uint2(pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv));
-            if (lse && g == 0) lse[((size_t)s * H + h) * L + q] = mx + __logf(sum);
+            for (int dt = 0; dt < 4; ++dt) {
+                w[dt][0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+                w[dt][1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+            }
+#pragma unroll
+            for (int dp = 0; dp < 2; ++dp) {
+                auto r0 = __builtin_amdgcn_permlane16_swap(w[2 * dp][0], w[2 * dp + 1][0], false, false);
+                auto r1 = __builtin_amdgcn_permlane16_swap(w[2 * dp][1], w[2 * dp + 1][1], false, false);
+                if (q < L) {
+                    bf16_t* orow = out + ((size_t)s * L + q) * Dm + h * 64 + (2 * dp + (g & 1)) * 16 + (g >> 1) * 8;
+                    *(uint4*)orow = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+            }
+            if (q < L && lse && g == 0) lse[((size_t)s * H + h) * L + q] = mx * scale + __logf(sum);
         }
     }
 }
