@@ -29,17 +29,32 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* base = qkv + (size_t)s * L * D3 + h * 64;
 
-    for (int c = tid; c < ATT_KROWS * 8; c += 192) {
-        const int r = c >> 3, ch = c & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < L) v = *(const uint4*)(base + (size_t)r * D3 + Dm + ch * 8);
-        *(uint4*)(sK + k_off(r, ch)) = v;
+    // K and V of the head: every load of a thread is requested before the first LDS write (sweep by sweep the HBM
+    // latencies were serialised)
+    constexpr int KS = ATT_KROWS * 8 / 192, VS = (ATT_VROWS * 8 + 191) / 192;
+    static_assert(ATT_KROWS * 8 % 192 == 0, "K staging sweeps");
+    uint4 rk[KS], rv[VS];
+#pragma unroll
+    for (int it = 0; it < KS; ++it) {
+        const int c = tid + it * 192, r = c >> 3, ch = c & 7;
+        rk[it] = make_uint4(0, 0, 0, 0);
+        if (r < L) rk[it] = *(const uint4*)(base + (size_t)r * D3 + Dm + ch * 8);
     }
-    for (int c = tid; c < ATT_VROWS * 8; c += 192) {
-        const int r = c >> 3, ch = c & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < L) v = *(const uint4*)(base + (size_t)r * D3 + 2 * Dm + ch * 8);
-        *(uint4*)(sV + v_off(r, ch)) = v;
+#pragma unroll
+    for (int it = 0; it < VS; ++it) {
+        const int c = tid + it * 192, r = c >> 3, ch = c & 7;
+        rv[it] = make_uint4(0, 0, 0, 0);
+        if (c < ATT_VROWS * 8 && r < L) rv[it] = *(const uint4*)(base + (size_t)r * D3 + 2 * Dm + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < KS; ++it) {
+        const int c = tid + it * 192;
+        *(uint4*)(sK + k_off(c >> 3, c & 7)) = rk[it];
+    }
+#pragma unroll
+    for (int it = 0; it < VS; ++it) {
+        const int c = tid + it * 192;
+        if (c < ATT_VROWS * 8) *(uint4*)(sV + v_off(c >> 3, c & 7)) = rv[it];
     }
     __syncthreads();
 
@@ -170,17 +185,48 @@ __device__ __forceinline__ int d_off(int row, int chunk) {
     return row * 128 + ((chunk ^ f) << 4);
 }
 
+// Store a 16-row x 64-column f32 accumulator tile (lane (fr, g): columns dt*16 + 4g .. +3 of row fr) as bf16 with
+// 16-B stores: lanes g / g^1 exchange halves (v_permlane16_swap, see gemm_bf16.hip) so a lane owns 8 consecutive columns.
+// `row` = this lane's row base (64 columns), `live` = the row exists; every lane must call it (the swap needs all).
+__device__ __forceinline__ void store_rows16(const f32x4_t (&o)[4], bf16_t* row, bool live, int g) {
+    uint32_t w[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        w[dt][0] = pack2bf(o[dt][0], o[dt][1]);
+        w[dt][1] = pack2bf(o[dt][2], o[dt][3]);
+    }
+#pragma unroll
+    for (int dp = 0; dp < 2; ++dp) {
+        auto r0 = __builtin_amdgcn_permlane16_swap(w[2 * dp][0], w[2 * dp + 1][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane16_swap(w[2 * dp][1], w[2 * dp + 1][1], false, false);
+        if (live) *(uint4*)(row + (2 * dp + (g & 1)) * 16 + (g >> 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+}
+
 #define ATB_ROWS 144  // 9 tiles; reads past it are clamped (they only ever meet zero probabilities)
+#ifdef SIG_ATTN_STAMPS   // diagnostic build only (tools/attn_stamps.py)
+__device__ unsigned long long g_astamps[4 * 4096];
+extern "C" int sig_debug_read_attn_stamps(unsigned long long* out, int nblocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_astamps), sizeof(unsigned long long) * 4 * nblocks) == hipSuccess ? 0 : 2;
+}
+#define ATT_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#else
+#define ATT_STAMP(v)
+#endif
 __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                        bf16_t* __restrict__ dqkv, int S, int L, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef SIG_ATTN_STAMPS
+    unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0;
+    ATT_STAMP(ta0);
+#endif
     char* sQ = smem;
     char* sK = smem + ATB_ROWS * 128;
     char* sV = smem + 2 * ATB_ROWS * 128;
     char* sG = smem + 3 * ATB_ROWS * 128;                 // dO
-    float* sLse = (float*)(smem + 4 * ATB_ROWS * 128);    // [160]
-    float* sDel = sLse + ATB_ROWS;                        // [160] delta = rowsum(dO * O)
+    float* sLse = (float*)(smem + 4 * ATB_ROWS * 128);    // [160] lse * log2(e), +inf for rows >= L
+    float* sDel = sLse + 160;                             // [160] delta = rowsum(dO * O) * scale
     const int s = blockIdx.x / H, h = blockIdx.x - s * H;
     const int Dm = H * 64, D3 = 3 * Dm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -188,23 +234,36 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
     const bf16_t* obase = out + (size_t)s * L * Dm + h * 64;
     const bf16_t* gbase = dout + (size_t)s * L * Dm + h * 64;
 
-    // 192 threads = 24 rows x 8 chunks per sweep; delta via an 8-lane xor reduction
-    for (int c = tid; c < ATB_ROWS * 8; c += 192) {
-        const int r = c >> 3, ch = c & 7;
-        uint4 vq = make_uint4(0, 0, 0, 0), vk = vq, vv = vq, vg = vq, vo = vq;
+    // 192 threads = 24 rows x 8 chunks per sweep, 6 sweeps; delta via an 8-lane xor reduction.  All 30 loads of a thread
+    // are requested before any is consumed: sweep by sweep, the six HBM latencies were serialised (22 k of the block's
+    // 70 k cycles, tools/attn_stamps.py).
+    static_assert(ATB_ROWS * 8 % 192 == 0, "staging sweeps");
+    constexpr int SWEEPS = ATB_ROWS * 8 / 192;
+    uint4 lq[SWEEPS], lk[SWEEPS], lv[SWEEPS], lg[SWEEPS], lo[SWEEPS];
+    float llse[SWEEPS];
+#pragma unroll
+    for (int it = 0; it < SWEEPS; ++it) {
+        const int c = tid + it * 192, r = c >> 3, ch = c & 7;
+        lq[it] = lk[it] = lv[it] = lg[it] = lo[it] = make_uint4(0, 0, 0, 0);
+        llse[it] = 0.f;
         if (r < L) {
-            vq = *(const uint4*)(base + (size_t)r * D3 + ch * 8);
-            vk = *(const uint4*)(base + (size_t)r * D3 + Dm + ch * 8);
-            vv = *(const uint4*)(base + (size_t)r * D3 + 2 * Dm + ch * 8);
-            vg = *(const uint4*)(gbase + (size_t)r * Dm + ch * 8);
-            vo = *(const uint4*)(obase + (size_t)r * Dm + ch * 8);
+            lq[it] = *(const uint4*)(base + (size_t)r * D3 + ch * 8);
+            lk[it] = *(const uint4*)(base + (size_t)r * D3 + Dm + ch * 8);
+            lv[it] = *(const uint4*)(base + (size_t)r * D3 + 2 * Dm + ch * 8);
+            lg[it] = *(const uint4*)(gbase + (size_t)r * Dm + ch * 8);
+            lo[it] = *(const uint4*)(obase + (size_t)r * Dm + ch * 8);
+            if (ch == 0) llse[it] = lse[((size_t)s * H + h) * L + r];
         }
+    }
+#pragma unroll
+    for (int it = 0; it < SWEEPS; ++it) {
+        const int c = tid + it * 192, r = c >> 3, ch = c & 7;
         const int off = d_off(r, ch);
-        *(uint4*)(sQ + off) = vq;
-        *(uint4*)(sK + off) = vk;
-        *(uint4*)(sV + off) = vv;
-        *(uint4*)(sG + off) = vg;
-        const uint32_t gw[4] = {vg.x, vg.y, vg.z, vg.w}, ow[4] = {vo.x, vo.y, vo.z, vo.w};
+        *(uint4*)(sQ + off) = lq[it];
+        *(uint4*)(sK + off) = lk[it];
+        *(uint4*)(sV + off) = lv[it];
+        *(uint4*)(sG + off) = lg[it];
+        const uint32_t gw[4] = {lg[it].x, lg[it].y, lg[it].z, lg[it].w}, ow[4] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w};
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -214,10 +273,14 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
         d += __shfl_xor(d, 4, 64);
-        if (ch == 0) {
-            sDel[r] = d;
-            sLse[r] = r < L ? lse[((size_t)s * H + h) * L + r] : 0.f;
+        if (ch == 0) {   // pre-scaled: p = 2^(s*c2 - lse*log2e), dS = p * (dP*scale - delta*scale); rows >= L give p = 0
+            sDel[r] = d * 0.125f;
+            sLse[r] = r < L ? llse[it] * 1.4426950408889634f : INFINITY;
         }
+    }
+    if (tid < 16) {       // rows 144..159: the tenth (non-existent) tile read by the paired k-steps
+        sLse[ATB_ROWS + tid] = INFINITY;
+        sDel[ATB_ROWS + tid] = 0.f;
     }
     __syncthreads();
 
@@ -226,6 +289,9 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
     const int tq = fr >> 2, tp = fr & 3;
     const float scale = 0.125f;
 
+#ifdef SIG_ATTN_STAMPS
+    ATT_STAMP(ta1);
+#endif
     // ------------------------------ pass A: dQ (wave owns query tiles) ------------------------------
     for (int qt = wave; qt < NT; qt += 3) {
         const int q = qt * 16 + fr;
@@ -235,7 +301,8 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
             qf[ks] = *(const bf16x8_t*)(sQ + d_off(q, (ks << 2) | g));
             gf[ks] = *(const bf16x8_t*)(sG + d_off(q, (ks << 2) | g));
         }
-        const float lq = sLse[q], dq_ = sDel[q];
+        const float lq2 = sLse[q], dqs = sDel[q];     // +inf / 0 for q >= L
+        const float c2 = scale * 1.4426950408889634f;
         f32x4_t ds[ATT_NT + 1];
 #pragma unroll
         for (int kt = 0; kt < ATT_NT; ++kt) {
@@ -251,9 +318,13 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int key = kt * 16 + 4 * g + e;
-                const float pv = (key < L && q < L) ? __expf(a[e] * scale - lq) : 0.f;
-                a[e] = pv * (b[e] - dq_) * scale;
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -lq2));
+                a[e] = pv * __builtin_fmaf(b[e], scale, -dqs);
+            }
+            if (kt * 16 + 16 > L) {   // uniform: the key tile that straddles L (and the ones past it)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kt * 16 + 4 * g + e >= L) a[e] = 0.f;
             }
             ds[kt] = a;
         }
@@ -266,9 +337,10 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
         for (int kk = 0; kk < (ATT_NT + 1) / 2; ++kk) {
             if (kk * 2 >= NT) break;
             const f32x4_t p0 = ds[2 * kk], p1 = ds[2 * kk + 1];
-            bf16x8_t pf;
-            pf[0] = (short)f2bf(p0[0]); pf[1] = (short)f2bf(p0[1]); pf[2] = (short)f2bf(p0[2]); pf[3] = (short)f2bf(p0[3]);
-            pf[4] = (short)f2bf(p1[0]); pf[5] = (short)f2bf(p1[1]); pf[6] = (short)f2bf(p1[2]); pf[7] = (short)f2bf(p1[3]);
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+            pk.w[0] = pack2bf(p0[0], p0[1]); pk.w[1] = pack2bf(p0[2], p0[3]);
+            pk.w[2] = pack2bf(p1[0], p1[1]); pk.w[3] = pack2bf(p1[2], p1[3]);
+            const bf16x8_t pf = pk.v;
             const int r0 = 32 * kk + 4 * g + tq;
             const int r1 = r0 + 16 < ATB_ROWS ? r0 + 16 : r0;  // tile 9 does not exist: its dS is 0
 #pragma unroll
@@ -280,14 +352,12 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, pf, o[dt], 0, 0, 0);
             }
         }
-        if (q < L) {
-            bf16_t* orow = dqkv + ((size_t)s * L + q) * D3 + h * 64 + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *(uint2*)(orow + dt * 16) = make_uint2(pack2bf(o[dt][0], o[dt][1]), pack2bf(o[dt][2], o[dt][3]));
-        }
+        store_rows16(o, dqkv + ((size_t)s * L + (q < L ? q : 0)) * D3 + h * 64, q < L, g);
     }
 
+#ifdef SIG_ATTN_STAMPS
+    ATT_STAMP(ta2);
+#endif
     // ------------------------------ pass B: dK, dV (wave owns key tiles) ------------------------------
     for (int kt = wave; kt < NT; kt += 3) {
         const int key = kt * 16 + fr;
@@ -297,6 +367,8 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
             kf[ks] = *(const bf16x8_t*)(sK + d_off(key, (ks << 2) | g));
             vf[ks] = *(const bf16x8_t*)(sV + d_off(key, (ks << 2) | g));
         }
+        const bool keyok = key < L;
+        const float c2 = scale * 1.4426950408889634f;
         f32x4_t dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -306,7 +378,7 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int qq = 0; qq < (ATT_NT + 1) / 2; ++qq) {  // query tiles (2qq, 2qq+1) = one 32-deep k-step
             if (qq * 2 >= NT) break;
-            bf16x8_t pf, sf;
+            uint32_t pw[4], sw[4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * qq + half;
@@ -320,16 +392,21 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
                         b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf[ks], b, 0, 0, 0);  // dP [row q][col key]
                     }
                 }
+                // 4 consecutive queries per lane: their pre-scaled lse / delta in one b128 read each (+inf / 0 past L)
+                const f32x4_t l4 = *(const f32x4_t*)(sLse + qt * 16 + 4 * g), d4 = *(const f32x4_t*)(sDel + qt * 16 + 4 * g);
+                float pv[4], dsv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int q = qt * 16 + 4 * g + e;
-                    const bool ok = (q < L) && (key < L) && (qt < NT);
-                    const float pv = ok ? __expf(a[e] * scale - sLse[ok ? q : 0]) : 0.f;
-                    const float dsv = pv * (b[e] - sDel[ok ? q : 0]) * scale;
-                    pf[half * 4 + e] = (short)f2bf(pv);
-                    sf[half * 4 + e] = (short)f2bf(dsv);
+                    pv[e] = keyok ? __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -l4[e])) : 0.f;
+                    dsv[e] = pv[e] * __builtin_fmaf(b[e], scale, -d4[e]);
                 }
+                pw[half * 2] = pack2bf(pv[0], pv[1]); pw[half * 2 + 1] = pack2bf(pv[2], pv[3]);
+                sw[half * 2] = pack2bf(dsv[0], dsv[1]); sw[half * 2 + 1] = pack2bf(dsv[2], dsv[3]);
             }
+            union { uint32_t w[4]; bf16x8_t v; } pu, su;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pu.w[e] = pw[e]; su.w[e] = sw[e]; }
+            const bf16x8_t pf = pu.v, sf = su.v;
             // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
             const int r0 = 32 * qq + 4 * g + tq;
             const int r1 = r0 + 16 < ATB_ROWS ? r0 + 16 : r0;  // query tile 9 does not exist: P = dS = 0 there
@@ -346,23 +423,25 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sf, dk[dt], 0, 0, 0);
             }
         }
-        if (key < L) {
-            bf16_t* krow = dqkv + ((size_t)s * L + key) * D3 + Dm + h * 64 + 4 * g;
-            bf16_t* vrow = krow + Dm;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                *(uint2*)(krow + dt * 16) = make_uint2(pack2bf(dk[dt][0], dk[dt][1]), pack2bf(dk[dt][2], dk[dt][3]));
-                *(uint2*)(vrow + dt * 16) = make_uint2(pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3]));
-            }
-        }
+        bf16_t* krow = dqkv + ((size_t)s * L + (keyok ? key : 0)) * D3 + Dm + h * 64;
+        store_rows16(dk, krow, keyok, g);
+        store_rows16(dv, krow + Dm, keyok, g);
     }
+#ifdef SIG_ATTN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_STAMP(ta3);
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_astamps[blockIdx.x * 4 + 0] = ta0; g_astamps[blockIdx.x * 4 + 1] = ta1;
+        g_astamps[blockIdx.x * 4 + 2] = ta2; g_astamps[blockIdx.x * 4 + 3] = ta3;
+    }
+#endif
 }
 
 int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
                         int S, int L, int H, hipStream_t st) {
     SIG_CHECK_ARG(qkv && out && dout && lse && dqkv, "attn_bwd: null pointer");
     SIG_CHECK_ARG(S > 0 && H > 0 && L > 0 && L <= ATT_KROWS, "attn_bwd: L=%d must be in 1..%d", L, ATT_KROWS);
-    const int lds = 4 * ATB_ROWS * 128 + 2 * ATB_ROWS * 4;
+    const int lds = 4 * ATB_ROWS * 128 + 2 * 160 * 4;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
