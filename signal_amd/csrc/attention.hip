@@ -10,6 +10,15 @@
 #include "sig_common.h"
 #include "sig_kernels.h"
 
+#ifdef SIG_ATTN_STAMPS   // diagnostic build only (tools/attn_stamps.py)
+__device__ unsigned long long g_astamps[4 * 4096];
+extern "C" int sig_debug_read_attn_stamps(unsigned long long* out, int nblocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_astamps), sizeof(unsigned long long) * 4 * nblocks) == hipSuccess ? 0 : 2;
+}
+#define ATT_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#else
+#define ATT_STAMP(v)
+#endif
 #define ATT_KROWS 144
 #define ATT_VROWS 160
 #define ATT_NT 9  // max 16-row tiles
@@ -22,6 +31,10 @@ __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((
 __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int S, int L, int H) {
     __shared__ __attribute__((aligned(16))) char smem[ATT_KROWS * 128 + ATT_VROWS * 128];
+#ifdef SIG_ATTN_STAMPS
+    unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0;
+    ATT_STAMP(ta0);
+#endif
     char* sK = smem;
     char* sV = smem + ATT_KROWS * 128;
     const int s = blockIdx.x / H, h = blockIdx.x - s * H;
@@ -60,6 +73,9 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
 
     const int fr = lane & 15, g = lane >> 4;
     const int NT = (L + 15) >> 4;
+#ifdef SIG_ATTN_STAMPS
+    ATT_STAMP(ta1);
+#endif
     const int tq = fr >> 2, tp = fr & 3;  // transposed-read address roles inside the 16-lane group
     const float scale = 0.125f;
 
@@ -156,6 +172,15 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
             if (q < L && lse && g == 0) lse[((size_t)s * H + h) * L + q] = mx * scale + __logf(sum);
         }
     }
+#ifdef SIG_ATTN_STAMPS
+    ATT_STAMP(ta2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_STAMP(ta3);
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_astamps[blockIdx.x * 4 + 0] = ta0; g_astamps[blockIdx.x * 4 + 1] = ta1;
+        g_astamps[blockIdx.x * 4 + 2] = ta2; g_astamps[blockIdx.x * 4 + 3] = ta3;
+    }
+#endif
 }
 
 int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, hipStream_t st) {
@@ -204,15 +229,6 @@ __device__ __forceinline__ void store_rows16(const f32x4_t (&o)[4], bf16_t* row,
 }
 
 #define ATB_ROWS 144  // 9 tiles; reads past it are clamped (they only ever meet zero probabilities)
-#ifdef SIG_ATTN_STAMPS   // diagnostic build only (tools/attn_stamps.py)
-__device__ unsigned long long g_astamps[4 * 4096];
-extern "C" int sig_debug_read_attn_stamps(unsigned long long* out, int nblocks) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_astamps), sizeof(unsigned long long) * 4 * nblocks) == hipSuccess ? 0 : 2;
-}
-#define ATT_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
-#else
-#define ATT_STAMP(v)
-#endif
 __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                        bf16_t* __restrict__ dqkv, int S, int L, int H) {

@@ -39,8 +39,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return *reinterpret_cast<bf16_t*>(&b);
 }
+// two floats -> one dword of two bf16 (lo in bits 0..15), round-to-nearest-even: ONE v_cvt_pk_bf16_f32.  (Converting the
+// halves separately and merging them cost a convert per value plus a shift and an OR per pair.)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef __bf16 bf16x2_native_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_native_t __attribute__((ext_vector_type(2)));
+    const f32x2_native_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_native_t));
 }
 
 // ---- wave reductions (64 lanes) ----------------------------------------------------------------

@@ -18,12 +18,18 @@ Mp = ops.pad_rows(S * L)
 qkv = torch.randn(Mp, 2304, device=dev).to(torch.bfloat16); o = torch.zeros(Mp, 768, device=dev, dtype=torch.bfloat16)
 lse = torch.zeros(S, H, L, device=dev); ops.attn_fwd(qkv, o, lse, S, L, H)
 do = torch.randn(Mp, 768, device=dev).to(torch.bfloat16); dqkv = torch.zeros_like(qkv)
+nb = S * H
+def read():
+    buf = (ctypes.c_ulonglong * (4 * nb))()
+    assert L_.sig_debug_read_attn_stamps(buf, nb) == 0
+    return torch.tensor(list(buf), dtype=torch.float64).view(nb, 4)
+for _ in range(3): ops.attn_fwd(qkv, o, lse, S, L, H)
+torch.cuda.synchronize()
+t = read()
+print(f"attn_fwd per block (cycles, median): staging {(t[:,1]-t[:,0]).median():.0f}  query tiles {(t[:,2]-t[:,1]).median():.0f}  store drain {(t[:,3]-t[:,2]).median():.0f}  total {(t[:,3]-t[:,0]).median():.0f}")
 for _ in range(3): ops.attn_bwd(qkv, o, do, lse, dqkv, S, L, H)
 torch.cuda.synchronize()
-nb = S * H
-buf = (ctypes.c_ulonglong * (4 * nb))()
-assert L_.sig_debug_read_attn_stamps(buf, nb) == 0
-t = torch.tensor(list(buf), dtype=torch.float64).view(nb, 4)
+t = read()
 st, pa, pb = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
 print(f"attn_bwd per block (cycles, median): staging {st.median():.0f}  pass A {pa.median():.0f}  pass B + drain {pb.median():.0f}  total {(t[:,3]-t[:,0]).median():.0f}")
 shutil.rmtree(tmp, ignore_errors=True)
