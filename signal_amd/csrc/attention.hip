@@ -28,7 +28,10 @@ extern "C" int sig_debug_read_attn_stamps(unsigned long long* out, int nblocks) 
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
 
-__global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// FULL: L in (128, 144], i.e. all nine 16-row tiles exist (every shipped config: L = 129) -- the per-tile guards fold away;
+// with a run-time tile count the ~50 live scalar conditions were spilled to VGPR lanes (v_writelane / v_readlane).
+template <bool FULL>
+__global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int S, int L, int H) {
     __shared__ __attribute__((aligned(16))) char smem[ATT_KROWS * 128 + ATT_VROWS * 128];
 #ifdef SIG_ATTN_STAMPS
@@ -72,13 +75,14 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
     __syncthreads();
 
     const int fr = lane & 15, g = lane >> 4;
-    const int NT = (L + 15) >> 4;
+    const int NT = FULL ? ATT_NT : (L + 15) >> 4;
 #ifdef SIG_ATTN_STAMPS
     ATT_STAMP(ta1);
 #endif
     const int tq = fr >> 2, tp = fr & 3;  // transposed-read address roles inside the 16-lane group
     const float scale = 0.125f;
 
+#pragma unroll 1   // (with a constant tile count the compiler would unroll the three tiles: 336 registers)
     for (int qt = wave; qt < NT; qt += 3) {
         const int q = qt * 16 + fr;
         const int qc = q < L ? q : L - 1;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int kt = 0; kt < ATT_NT; ++kt) {
             f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-            if (kt < NT) {
+            if (FULL || kt < NT) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(kt * 16 + fr, (ks << 2) | g));
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < (ATT_NT + 1) / 2; ++kk) {
-            if (kk * 2 >= NT) break;
+            if (!FULL && kk * 2 >= NT) break;
             const f32x4_t p0 = sc[2 * kk], p1 = sc[2 * kk + 1];
             union { uint32_t w[4]; bf16x8_t v; } pk;
             pk.w[0] = pack2bf(p0[0], p0[1]); pk.w[1] = pack2bf(p0[2], p0[3]);
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(192) void attn_fwd_kernel(const bf16_t* __restrict_
 int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, hipStream_t st) {
     SIG_CHECK_ARG(qkv && out, "attn_fwd: null pointer");
     SIG_CHECK_ARG(S > 0 && H > 0 && L > 0 && L <= ATT_KROWS, "attn_fwd: L=%d must be in 1..%d", L, ATT_KROWS);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
+    if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
     SIG_CHECK_LAUNCH("attn_fwd");
     return 0;
 }
@@ -229,7 +234,8 @@ __device__ __forceinline__ void store_rows16(const f32x4_t (&o)[4], bf16_t* row,
 }
 
 #define ATB_ROWS 144  // 9 tiles; reads past it are clamped (they only ever meet zero probabilities)
-__global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+template <bool FULL>
+__global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                        bf16_t* __restrict__ dqkv, int S, int L, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
     __syncthreads();
 
     const int fr = lane & 15, g = lane >> 4;
-    const int NT = (L + 15) >> 4;
+    const int NT = FULL ? ATT_NT : (L + 15) >> 4;
     const int tq = fr >> 2, tp = fr & 3;
     const float scale = 0.125f;
 
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
     ATT_STAMP(ta1);
 #endif
     // ------------------------------ pass A: dQ (wave owns query tiles) ------------------------------
+#pragma unroll 1   // (with a constant tile count the compiler would unroll the three tiles: 336 registers)
     for (int qt = wave; qt < NT; qt += 3) {
         const int q = qt * 16 + fr;
         bf16x8_t qf[2], gf[2];
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int kt = 0; kt < ATT_NT; ++kt) {
             f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (kt < NT) {
+            if (FULL || kt < NT) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8_t kf = *(const bf16x8_t*)(sK + d_off(kt * 16 + fr, (ks << 2) | g));
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < (ATT_NT + 1) / 2; ++kk) {
-            if (kk * 2 >= NT) break;
+            if (!FULL && kk * 2 >= NT) break;
             const f32x4_t p0 = ds[2 * kk], p1 = ds[2 * kk + 1];
             union { uint32_t w[4]; bf16x8_t v; } pk;
             pk.w[0] = pack2bf(p0[0], p0[1]); pk.w[1] = pack2bf(p0[2], p0[3]);
@@ -375,7 +382,11 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
     ATT_STAMP(ta2);
 #endif
     // ------------------------------ pass B: dK, dV (wave owns key tiles) ------------------------------
-    for (int kt = wave; kt < NT; kt += 3) {
+    // (run-time tile count here even when FULL: with the guards folded the two accumulator sets and the fully unrolled
+    //  k-steps need 336 registers -- 80 spills, pass B 18 k -> 49 k cycles)
+    const int NTb = (L + 15) >> 4;
+#pragma unroll 1
+    for (int kt = wave; kt < NTb; kt += 3) {
         const int key = kt * 16 + fr;
         bf16x8_t kf[2], vf[2];
 #pragma unroll
@@ -393,13 +404,13 @@ __global__ __launch_bounds__(192) void attn_bwd_kernel(const bf16_t* __restrict_
         }
 #pragma unroll
         for (int qq = 0; qq < (ATT_NT + 1) / 2; ++qq) {  // query tiles (2qq, 2qq+1) = one 32-deep k-step
-            if (qq * 2 >= NT) break;
+            if (qq * 2 >= NTb) break;
             uint32_t pw[4], sw[4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * qq + half;
                 f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-                if (qt < NT) {
+                if (qt < NTb) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         const bf16x8_t qf = *(const bf16x8_t*)(sQ + d_off(qt * 16 + fr, (ks << 2) | g));
@@ -460,10 +471,12 @@ int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
     const int lds = 4 * ATB_ROWS * 128 + 2 * 160 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
+    if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
+    else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
     SIG_CHECK_LAUNCH("attn_bwd");
     return 0;
 }
