@@ -23,9 +23,13 @@
 // LDS image of one operand tile: 128 rows x 64 k (bf16) = 128 B per row, 8 chunks of 16 B.
 // physical chunk = chunk ^ ((row >> 1) & 7): a ds_read_b128 lane group (rows r..r+15 at chunk c and
 // c+1, MI355X_MICROARCH LDS table) then covers all 16 slots of the 256-B bank row exactly once.
-__device__ __forceinline__ float quick_gelu_f(float u) { return u / (1.0f + __expf(-1.702f * u)); }
+// sigmoid(1.702 u) = 1 / (1 + 2^(-1.702 log2(e) u)): one multiply, v_exp_f32, one add, v_rcp_f32
+__device__ __forceinline__ float quick_sigmoid_f(float u) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -2.4554669595930156f));
+}
+__device__ __forceinline__ float quick_gelu_f(float u) { return u * quick_sigmoid_f(u); }
 __device__ __forceinline__ float quick_gelu_grad_f(float u) {
-    const float s = 1.0f / (1.0f + __expf(-1.702f * u));
+    const float s = quick_sigmoid_f(u);
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
 
@@ -73,6 +77,7 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
 #pragma unroll
     for (int j = 0; j < TN; ++j) csum[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bool save_u = GELU_FWD && p.aux != nullptr;
+    const bool do_sum = p.colsum != nullptr;
     // GELU': the whole tile's saved pre-activations are requested before anything is consumed (TM*TN/2 16-B loads per
     // lane, in the registers the operand fragments no longer need) -- inside the store loop their latency was exposed
     // once per 16-row group
@@ -125,7 +130,7 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
                 pk[j][0] = pack2bf(x[0], x[1]);
                 pk[j][1] = pack2bf(x[2], x[3]);
             }
-            if (live) csum[j] += x;
+            if (do_sum && live) csum[j] += x;   // (uniform flag: forward GEMMs request no column sums)
         }
         if (!OUT_F32) {
 #pragma unroll
