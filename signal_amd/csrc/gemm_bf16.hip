@@ -170,9 +170,9 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
 }
 
 #ifdef SIG_GEMM_STAMPS   // diagnostic build only (tools/gemm_stamps.py): where does a tile's time go?
-__device__ unsigned long long g_stamps[4 * 8192];
+__device__ unsigned long long g_stamps[5 * 8192];
 extern "C" int sig_debug_read_stamps(unsigned long long* out, int nblocks) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4 * nblocks) == hipSuccess ? 0 : 2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (nblocks > 0 ? 4 * nblocks : 5 * 8192)) == hipSuccess ? 0 : 2;
 }
 #endif
 
@@ -375,11 +375,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     }
     }
 #ifdef SIG_GEMM_STAMPS
+    unsigned long long ts2b = 0;
+    SIG_STAMP(ts2b);                                    // every store ISSUED
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SIG_STAMP(ts3);
+    SIG_STAMP(ts3);                                     // every store acknowledged
     if (tid == 0 && blockIdx.x < 8192) {
         g_stamps[blockIdx.x * 4 + 0] = ts0; g_stamps[blockIdx.x * 4 + 1] = ts1;
         g_stamps[blockIdx.x * 4 + 2] = ts2; g_stamps[blockIdx.x * 4 + 3] = ts3;
+        g_stamps[4 * 8192 + blockIdx.x] = ts2b;
     }
 #endif
 }

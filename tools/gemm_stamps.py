@@ -29,12 +29,17 @@ for name, n, k, epi in [("qkv", 2304, 768, ops.BIAS_BF16), ("c_fc", 3072, 768, o
     torch.cuda.synchronize()
     T = int(os.environ.get('SIG_GEMM_TILE', '128'))
     nb = min(8192, (Mp // T) * (n // T))
-    buf = (ctypes.c_ulonglong * (4 * nb))()
-    assert L.sig_debug_read_stamps(buf, nb) == 0
-    t = torch.tensor(list(buf), dtype=torch.float64).view(nb, 4)
-    t = t[(t[:, 0] > 0)]
+    big = (ctypes.c_ulonglong * (5 * 8192))()
+    assert L.sig_debug_read_stamps(big, 0) == 0
+    allv = torch.tensor(list(big), dtype=torch.float64)
+    t = allv[:4 * nb].view(nb, 4)
+    issued = allv[4 * 8192:4 * 8192 + nb]
+    ok = t[:, 0] > 0
+    issued = issued[ok]
+    t = t[ok]
+    extra = f"  [stores issued after {(issued - t[:, 2]).median():.0f}, acknowledged {(t[:, 3] - issued).median():.0f} later]" if float(issued.max()) > 0 else ""
     pro, loop, epi_t = (t[:, 1] - t[:, 0]), (t[:, 2] - t[:, 1]), (t[:, 3] - t[:, 2])
     span = (t[:, 3].max() - t[:, 0].min())
     print(f"{name:7s} tiles {nb:5d}  per-tile cycles: prologue {pro.median():8.0f}  main loop {loop.median():8.0f} ({loop.median()/(k//64):6.0f}/k-step)"
-          f"  epilogue+drain {epi_t.median():8.0f}  total {(t[:,3]-t[:,0]).median():8.0f}")
+          f"  epilogue+drain {epi_t.median():8.0f}  total {(t[:,3]-t[:,0]).median():8.0f}" + extra)
 shutil.rmtree(tmp, ignore_errors=True)
