@@ -28,14 +28,29 @@ __global__ __launch_bounds__(512) void sim_qprime_kernel(const float* __restrict
     g[tid] = tokens[(size_t)s * L * SIM_D + tid];
     __syncthreads();
     const float4 g0 = *(const float4*)&g[lane * 8], g1 = *(const float4*)&g[lane * 8 + 4];
-    for (int o = wave; o < SIM_D; o += 8) {
-        const float4 w0 = *(const float4*)(Wq + (size_t)o * SIM_D + lane * 8), w1 = *(const float4*)(Wq + (size_t)o * SIM_D + lane * 8 + 4);
-        float acc = w0.x * g0.x + w0.y * g0.y + w0.z * g0.z + w0.w * g0.w + w1.x * g1.x + w1.y * g1.y + w1.z * g1.z + w1.w * g1.w;
-        acc = wave_sum(acc);
-        if (lane == 0) q[o] = acc + bq[o];
+    // 64 outputs per wave, 8 at a time: the 16 row loads of a batch are requested before the first reduction (one by one,
+    // the 64 L2 latencies were serialised).  Per output the arithmetic and its order are unchanged -- the selection
+    // downstream is compared bit-exactly with the reference.
+    for (int ob = wave; ob < SIM_D; ob += 64) {
+        float4 w0[8], w1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = ob + u * 8;
+            w0[u] = *(const float4*)(Wq + (size_t)o * SIM_D + lane * 8);
+            w1[u] = *(const float4*)(Wq + (size_t)o * SIM_D + lane * 8 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = ob + u * 8;
+            float acc = w0[u].x * g0.x + w0[u].y * g0.y + w0[u].z * g0.z + w0[u].w * g0.w + w1[u].x * g1.x + w1[u].y * g1.y +
+                        w1[u].z * g1.z + w1[u].w * g1.w;
+            acc = wave_sum(acc);
+            if (lane == 0) q[o] = acc + bq[o];
+        }
     }
     __syncthreads();
     float acc = 0.f;
+#pragma unroll 16
     for (int o = 0; o < SIM_D; ++o) acc += Wk[(size_t)o * SIM_D + tid] * q[o];
     qprime[((size_t)b * 3 + m) * SIM_D + tid] = acc;
     float c = wave_sum(q[tid] * bk[tid]);
@@ -120,6 +135,7 @@ __global__ __launch_bounds__(256) void sim_select_kernel(const float* __restrict
         if (tid < Lp) {
             const float v = pi[m][tid];
             int rank = 0;
+#pragma unroll 16   // independent broadcast LDS reads: without unrolling each iteration paid the LDS latency
             for (int j = 0; j < Lp; ++j) {
                 const float o = pi[m][j];
                 rank += (o > v) || (o == v && j < tid);
@@ -133,10 +149,18 @@ __global__ __launch_bounds__(256) void sim_select_kernel(const float* __restrict
         if (tid < 2 * Lp) {
             const int mt = tid < Lp ? oa : ob, jt = tid < Lp ? tid : tid - Lp;
             const float v = pc[m][mt * Lp + jt];
-            int rank = 0;
-            for (int j = 0; j < 2 * Lp; ++j) {
-                const float o = pc[m][(j < Lp ? oa : ob) * Lp + (j < Lp ? j : j - Lp)];
+            int rank = 0;   // candidate list = [oa's Lp scores | ob's Lp scores]; ties go to the lower list index
+            const float* la = &pc[m][oa * Lp];
+            const float* lb = &pc[m][ob * Lp];
+#pragma unroll 16
+            for (int j = 0; j < Lp; ++j) {
+                const float o = la[j];
                 rank += (o > v) || (o == v && j < tid);
+            }
+#pragma unroll 16
+            for (int j = 0; j < Lp; ++j) {
+                const float o = lb[j];
+                rank += (o > v) || (o == v && j + Lp < tid);
             }
             if (rank < k2) sel[mt][jt] = 1;  // benign race: every writer stores 1
         }
