@@ -176,8 +176,17 @@ extern "C" int sig_debug_read_stamps(unsigned long long* out, int nblocks) {
 }
 #endif
 
-template <int EPI>
+// BM x 128 x 64 tile, BM = 128 or 160.  BM = 160 exists for tile-count quantisation: the 768-column GEMMs at M = 24768
+// are 1164 tiles of 128x128 = 3 rounds of the chip's 512 slots, but 930 tiles of 160x128 = 2 rounds of 1.25x the work
+// (the same step at B = 128 per GPU, twice the tiles, runs 9 % more triplets per second).  Wave tile (BM/2) x 64 =
+// 5 x 4 MFMA tiles with 9 fragment reads per 20 MFMAs (8 per 16 at BM = 128); LDS 2 x 36 KB, still two blocks per CU.
+template <int EPI, int BM>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
+    static_assert(BM == 128 || BM == 160, "row tile");
+    constexpr int TM = BM / 32;              // 16-row MFMA tiles per wave (wave tile = BM/2 rows x 64 columns)
+    constexpr int PA = BM / 32;              // A pieces (8 rows x 128 B) per wave and stage; B: 4
+    constexpr int AB = BM * 128;             // bytes of the A image
+    constexpr int STAGE = AB + 16384;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, in an SGPR (LDS-DMA base goes to M0)
@@ -187,40 +196,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int per = tm * wb, bnd = id / per, rr = id - bnd * per;
     const int tile_m = rr / wb, tile_n = bnd * wb + (rr - tile_m * wb);
-    const int m0 = tile_m << 7, n0 = tile_n << 7;
+    const int m0 = tile_m * BM, n0 = tile_n << 7;
 
-    // ---- staging: wave w moves pieces w*4..w*4+3 (8 rows x 128 B each) of A and of Bt ----
-    const bf16_t* ag[4];
+    // ---- staging: wave w moves A pieces w*PA.., B pieces w*4.. (8 rows x 128 B each) ----
+    const bf16_t* ag[PA];
     const bf16_t* bg[4];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int r = (wave * PA + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        ag[j] = p.A + (size_t)(m0 + r) * p.lda + c * 8;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (wave * 4 + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        ag[j] = p.A + (size_t)(m0 + r) * p.lda + c * 8;
         bg[j] = p.Bt + (size_t)(n0 + r) * p.ldb + c * 8;
     }
     auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * 32768 + wave * 4096;
+        char* sa = smem + stage * STAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16_untracked(ag[j] + kt * 64, sa + j * 1024);
+        for (int j = 0; j < PA; ++j) glds16_untracked(ag[j] + kt * 64, sa + (wave * PA + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16_untracked(bg[j] + kt * 64, sa + 16384 + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_untracked(bg[j] + kt * 64, sa + AB + (wave * 4 + j) * 1024);
     };
 
-    // ---- fragment read offsets (bytes inside one operand tile) ----
+    // ---- fragment read offsets (bytes inside one stage) ----
     const int fr = lane & 15, g = lane >> 4, sw = fr >> 1;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
     int aoff[2], boff[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int ch = (((ks << 2) | g) ^ sw) << 4;
-        aoff[ks] = (wm + fr) * 128 + ch;
-        boff[ks] = 16384 + (wn + fr) * 128 + ch;
+        aoff[ks] = (wm + fr) * 128 + ch;      // (wm + i*16 + fr) >> 1 & 7 == fr >> 1 & 7: wm and i*16 are multiples of 16
+        boff[ks] = AB + (wn + fr) * 128 + ch;
     }
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -240,14 +254,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
         if (kt == 0) SIG_STAMP(ts1);
 #endif
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* s = smem + (kt & 1) * 32768;
-        // all 16 fragments of the K-step are requested up front (the DMA is issued untracked, so the compiler's waits
+        const char* s = smem + (kt & 1) * STAGE;
+        // all fragments of the K-step are requested up front (the DMA is issued untracked, so the compiler's waits
         // are counted: the first MFMAs start when the ks = 0 fragments are in, the ks = 1 reads land under them)
-        bf16x8_t af[2][4], bf[2][4];
+        bf16x8_t af[2][TM], bf[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[ks][i] = *(const bf16x8_t*)(s + aoff[ks] + i * 2048);
+            for (int i = 0; i < TM; ++i) af[ks][i] = *(const bf16x8_t*)(s + aoff[ks] + i * 2048);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[ks][j] = *(const bf16x8_t*)(s + boff[ks] + j * 2048);
         }
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
@@ -268,111 +282,67 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
 #endif
     // ---- epilogue ----
     // bf16 outputs: straight from the accumulator registers (epilogue_regs above: no LDS, no barrier; qkv epilogue
-    // 5960 -> 3476 cycles per tile).  f32 outputs keep the LDS transpose below: a lane of the MFMA layout only holds 16 B
+    // 5960 -> 3476 cycles per tile).  f32 outputs go through an LDS transpose: a lane of the MFMA layout only holds 16 B
     // of an f32 row, so register stores make 64-B runs and measured slower (c_proj 11.1k -> 18.1k cycles).
     constexpr bool OUT_F32 = EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32;
     if constexpr (!OUT_F32) {
-        epilogue_regs<EPI, 4, 4>(p, acc, m0 + wm, n0 + wn, lane);
+        epilogue_regs<EPI, TM, 4>(p, acc, m0 + wm, n0 + wn, lane);
     } else {
-    // The MFMA result has a lane holding 4 columns of 16 DIFFERENT rows: storing it directly is 16 (32 with the saved
-    // pre-activation) store instructions per lane that each touch 16 rows x 32 B -- partial cache lines and a
-    // store-issue-bound tail that cost about as much as the whole K = 768 main loop (cdna guide T21).  Instead the
-    // wave transposes its 64x64 f32 sub-tile through the now idle LDS (two 32-row passes, 68-float padded rows:
-    // conflict-free b128 writes and reads) so a lane owns 8 CONSECUTIVE columns of one row: half the store
-    // instructions, each a full 128-B (bf16) / 256-B (f32) row segment per 8 lanes.
-    const int t8 = lane & 7, tr = lane >> 3;           // 8 lanes per row, 8 rows per instruction
-    const int n = n0 + wn + t8 * 8;
-    // residual rows of this lane requested before the barrier and the staging, so their latency is off the store path
-    f32x4_t rres[2][4][2];
-    if (EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
+        // The wave transposes its (BM/2) x 64 f32 sub-tile through the now idle LDS, 16 rows per pass (68-float padded
+        // rows: conflict-free b128 writes and reads, wave-private area) so a lane owns 8 CONSECUTIVE columns of one row:
+        // full 256-B row segments per 8 lanes.  The residual rows are requested before the barrier and the staging.
+        constexpr bool HAS_RES = EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32;
+        constexpr bool HAS_BIAS = EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32;
+        const int t8 = lane & 7, tr = lane >> 3;           // 8 lanes per row, 8 rows per instruction
+        const int n = n0 + wn + t8 * 8;
+        f32x4_t rres[HAS_RES ? TM : 1][2][2];
+        if (HAS_RES) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m0 + wm + half * 32 + q * 8 + tr;
-                const float* r = p.res + (size_t)(m < p.M ? m : 0) * p.ldr + n;   // rows past M: any valid row, never used
-                rres[half][q][0] = *(const f32x4_t*)r;
-                rres[half][q][1] = *(const f32x4_t*)(r + 4);
-            }
-    }
-    __syncthreads();                                   // every wave is done reading operand fragments
-    float* stg = (float*)(smem + wave * (32 * 68 * 4));  // this wave's private staging area
-    float bias8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if (EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_BIAS_GELU_BF16 ||
-        EPI == SIG_EPI_BIAS_GELUERF_BF16) {
-        const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
-    }
-    float csum[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *(f32x4_t*)(stg + (ii * 16 + fr) * 68 + j * 16 + g * 4) = acc[half * 2 + ii][j];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: in-order LDS, no barrier needed
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = q * 8 + tr;
-            const int m = m0 + wm + half * 32 + row;
-            float v[8];
-            {
-                const f32x4_t v0 = *(const f32x4_t*)(stg + row * 68 + t8 * 8), v1 = *(const f32x4_t*)(stg + row * 68 + t8 * 8 + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
-            }
-            if (m >= p.M) continue;
-            if (EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += rres[half][q][0][e]; v[4 + e] += rres[half][q][1][e]; }
-            }
-            if (EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) {
-                if (p.aux)   // pre-activation kept for backward
-                    *(uint4*)((bf16_t*)p.aux + (size_t)m * p.ldaux + n) =
-                        make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = EPI == SIG_EPI_BIAS_GELU_BF16 ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
-            }
-            if (EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_DGELUERF_BF16) {
-                const uint4 u = *(const uint4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
-                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u0 = bf2f((bf16_t)(w[e] & 0xffff)), u1 = bf2f((bf16_t)(w[e] >> 16));
-                    v[2 * e] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(u0) : gelu_erf_grad_f(u0);
-                    v[2 * e + 1] *= EPI == SIG_EPI_DGELU_BF16 ? quick_gelu_grad_f(u1) : gelu_erf_grad_f(u1);
+                for (int q = 0; q < 2; ++q) {
+                    const int m = m0 + wm + i * 16 + q * 8 + tr;
+                    const float* r = p.res + (size_t)(m < p.M ? m : 0) * p.ldr + n;   // rows past M: any valid row, never used
+                    rres[HAS_RES ? i : 0][q][0] = *(const f32x4_t*)r;
+                    rres[HAS_RES ? i : 0][q][1] = *(const f32x4_t*)(r + 4);
                 }
-            }
-            if (EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32) {
+        }
+        __syncthreads();                                   // every wave is done reading operand fragments
+        float* stg = (float*)(smem + wave * (16 * 68 * 4));  // this wave's private staging area
+        f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (HAS_BIAS) { b0 = *(const f32x4_t*)(p.bias + n); b1 = *(const f32x4_t*)(p.bias + n + 4); }
+        f32x4_t cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4_t*)(stg + fr * 68 + j * 16 + g * 4) = acc[i][j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: in-order LDS, no barrier needed
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int row = q * 8 + tr;
+                const int m = m0 + wm + i * 16 + row;
+                f32x4_t v0 = *(const f32x4_t*)(stg + row * 68 + t8 * 8) + b0, v1 = *(const f32x4_t*)(stg + row * 68 + t8 * 8 + 4) + b1;
+                if (m >= p.M) continue;
+                if (HAS_RES) { v0 += rres[HAS_RES ? i : 0][q][0]; v1 += rres[HAS_RES ? i : 0][q][1]; }
                 float* o = (float*)p.out + (size_t)m * p.ldo + n;
-                *(f32x4_t*)o = (f32x4_t){v[0], v[1], v[2], v[3]};
-                *(f32x4_t*)(o + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
-            } else {
-                *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + n) =
-                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+                *(f32x4_t*)o = v0;
+                *(f32x4_t*)(o + 4) = v1;
+                cs0 += v0;
+                cs1 += v1;
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the area
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the second pass overwrites the area
-    }
-    // optional bias-gradient by-product: column sums of what was just written (this wave's 64 rows x 64 columns)
-    if (p.colsum) {
+        // optional bias-gradient by-product: column sums of what was just written (this wave's rows x 64 columns)
+        if (p.colsum) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = csum[e];
-            t += __shfl_xor(t, 8, 64);
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            if (tr == 0) atomicAdd(p.colsum + n + e, t);
+            for (int e = 0; e < 8; ++e) {
+                float t = e < 4 ? cs0[e & 3] : cs1[e & 3];
+                t += __shfl_xor(t, 8, 64);
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                if (tr == 0) atomicAdd(p.colsum + n + e, t);
+            }
         }
-    }
     }
 #ifdef SIG_GEMM_STAMPS
     unsigned long long ts2b = 0;
@@ -386,7 +356,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     }
 #endif
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // 256x256 tile, 8 waves (2 x 4), 128x64 per wave, phase-pipelined.
@@ -631,11 +600,22 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     } else {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
             attr_done = true;
         }
         p.band = choose_band(p.N >> 7, p.K, 128);
-        hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3((mp >> 7) * (p.N >> 7)), dim3(256), 65536, st, p);
+        // 160-row tiles when they need fewer rounds of the chip's 512 slots per unit of work (1.25x a 128-row tile) and
+        // their last tile stays inside the 128-row padding of the operand buffers
+        const int tn128 = p.N >> 7, t128 = (mp >> 7) * tn128, tm160 = (p.M + 159) / 160, t160 = tm160 * tn128;
+        const float c128 = (float)((t128 + 511) / 512), c160 = 1.25f * (float)((t160 + 511) / 512);
+        bool tall = tm160 * 160 <= mp && c160 < c128;
+        static int force_bm = -1;
+        if (force_bm < 0) { const char* e = getenv("SIG_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
+        if (force_bm == 128) tall = false;
+        if (force_bm == 160) tall = tm160 * 160 <= mp;
+        if (tall) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 160>), dim3(t160), dim3(256), 73728, st, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 128>), dim3(t128), dim3(256), 65536, st, p);
     }
     if (timed) {
         (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
