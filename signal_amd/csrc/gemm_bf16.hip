@@ -1000,7 +1000,8 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
     if (force < 0) { const char* e = getenv("SIG_GEMM_TN_TILE"); force = e ? atoi(e) : 0; }
     // 256x256 tiles for the large weight gradients (one block per CU, <= 256 blocks); the rest on 128x128 tiles
     const bool can256 = (p.I & 255) == 0 && (p.J & 255) == 0 && (p.I >> 8) * (p.J >> 8) <= 128;
-    bool big = can256 && (size_t)p.I * p.J >= (size_t)1536 * 768 && ksteps >= 64;
+    // (also the small square ones: 768x768 out_proj wgrad 63.7 -> 48.2 us) as long as a row chunk keeps >= 8 K-steps
+    bool big = can256 && ksteps >= 64 && (long long)ksteps * ((p.I >> 8) * (p.J >> 8)) >= 2048;
     if (force == 128) big = false;
     if (force == 256) big = can256;
     if (big) {
