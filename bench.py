@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: RGB+NIR+TIR triplets per second at B=64 per GPU on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fwd_sim|train] [--batch 64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16] [--batch 64]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic triplets already resident in HBM:
-  fwd_sim : BASELINE.json configs[1] -- three-stream ViT-B/16 forward + SIM (token selection + interaction)
-  train   : BASELINE.json configs[2] -- full Signal train step (forward, SIM+GAM+LAM, ID+triplet loss, backward,
-            Adam), data-parallel over the ranks with gradients all-reduced over RCCL
-Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel (the c_fc GEMM, M=24768 N=3072 K=768 with the
-fused bias+QuickGELU epilogue) timed live with HIP events on its launch stream during the timed steps;
-`cpu_baseline` = the CPU oracle (oracle/signal_ref.py, a port of the reference's PyTorch CPU path) on this
-box's host cores on a bounded sample of the same workload."""
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a torch.distributed.run child,
+before this process touches the GPU) and relays rank 0's JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic triplets already resident in HBM.  The headline
+value is the TRAIN step (BASELINE.json configs[2]; configs[3] at N > 1): forward of the three-stream ViT-B/16 +
+SIM + GAM + LAM, ID + triplet loss, backward, fused Adam, gradients all-reduced over RCCL while the backward
+still runs.  The forward-only configuration (configs[1]: three-stream forward + SIM) is timed in the same run and
+reported in the `fwd_sim` sub-object.  `roofline` = the dominant kernel of the train step, timed live with HIP events
+on its launch stream during the timed steps; `cpu_baseline` = the CPU oracle (oracle/signal_ref.py, a port of the
+reference's PyTorch CPU path) running the same train step at B = 8 (configs[0]) on this box's host cores."""
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +29,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_MFMA_TFLOPS = 2500.0   # MI355X dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PROF_TN256 = 100            # sig_prof_begin class id: gemm_tn256_kernel (weight gradients), any shape
 
 
 def parse():
@@ -33,19 +38,40 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("SIGNAL_BENCH_WORKLOAD", "fwd_sim"), choices=["fwd_sim", "train"])
+    ap.add_argument("--workload", default=os.environ.get("SIGNAL_BENCH_WORKLOAD", "train"), choices=["train", "fwd_sim"],
+                    help="headline workload (train = configs[2]/[3]; fwd_sim = configs[1] only, no collective)")
+    ap.add_argument("--dtype", default=os.environ.get("SIGNAL_HIP_DTYPE", "bf16"), choices=["bf16", "fp16"],
+                    help="MFMA operand type (fp32 accumulate, residual stream, LayerNorm and softmax either way); "
+                         "fp16 trains with dynamic loss scaling like the reference's AMP GradScaler")
     ap.add_argument("--batch", type=int, default=64, help="triplets per GPU (metric is quoted at 64)")
+    ap.add_argument("--backend", default=os.environ.get("SIGNAL_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="collective backend; gloo lets several ranks share one GPU (tests only: RCCL needs a device per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fwd-sim", action="store_true", help="skip the forward-only sub-measurement")
     ap.add_argument("--h2d", action="store_true", help="also report the rate with batches coming from pinned host memory "
                     "through signal_amd.data.DevicePrefetcher (PCIe-inclusive; never the headline value)")
     return ap.parse_args()
 
 
-def build_model(dev, workload):
+def spawn_ranks(args) -> int:
+    """--gpus N without a launcher: start the N ranks as ONE child (torch.distributed.run) before anything here has
+    touched the GPU, relay its output, return its exit code.  Never exec: this process stays the parent."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def build_model(dev, dtype):
     from signal_amd.config import get_cfg_defaults
     from signal_amd.modeling import make_frame
     cfg = get_cfg_defaults()
     cfg.merge_from_file(os.path.join(ROOT, "configs", "RGBNT201", "Signal.yml"))
+    cfg.MODEL.OPERAND_DTYPE = dtype
     cfg.freeze()
     torch.manual_seed(1234)
     model = make_frame(cfg, num_class=171, camera_num=4, view_num=0).to(dev)
@@ -75,7 +101,7 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("SIGNAL_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(workload, budget_s=15.0):
+def cpu_baseline(workload, budget_s=20.0):
     """CPU oracle on the host cores, bounded sample: B=8 triplets (configs[0] of BASELINE.json)."""
     from oracle import signal_ref as O
     cores = host_cores()
@@ -110,89 +136,147 @@ def cpu_baseline(workload, budget_s=15.0):
         if el > budget_s or n >= 50:
             break
     return {"value": round(8 * n / el, 3), "unit": "triplets/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of B=8 synthetic 256x128 triplets, {what}, torch CPU {torch.get_num_threads()} threads"}
+            "sample": f"{n} steps of B=8 synthetic 256x128 triplets (configs[0]), {what}, torch CPU {torch.get_num_threads()} threads"}
+
+
+def committed_traffic(kernel_key):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md + WRITE_SIZE; tools/ab_profile.sh).  PMC counters cannot be read from inside this process, so
+    the JSON line carries the committed figure and says where it came from; null when no profile covers the kernel."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            ent = d.get("kernels", {}).get(kernel_key)
+            if ent:
+                return ent.get("bytes_per_launch"), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
+    return None, None
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev == 0 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (signal_amd has no CPU path)")
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, {ndev} visible (use --backend gloo to share a GPU in tests)")
+    dev = torch.device("cuda", local % ndev)
+    torch.cuda.set_device(dev)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (signal_amd has no CPU path)")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     from signal_amd import _lib, ops
 
-    cfg, model = build_model(dev, args.workload)
+    cfg, model = build_model(dev, args.dtype)
     B = args.batch
     img, vid, cam = synthetic(cfg, B, dev, 1234 + rank)
+    D, Fd, L = model.hip.D, model.hip.F, model.hip.L
+    M = 3 * B * L
 
-    if args.workload == "fwd_sim":
-        def step():
-            with torch.no_grad():
-                return model(img, cam_label=cam, training=False)
-        parallelism = f"dp{world} (independent shards, no collective)"
-    else:
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(el):
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def timed(step, steps, warmup, prof=None):
+        for _ in range(warmup):
+            step()
+        barrier()
+        if prof:
+            _lib.call("sig_prof_begin", *prof, 64 * steps + 8)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        el = time.perf_counter() - t0
+        res = None
+        if prof:
+            ms, n, fl = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+            _lib.call("sig_prof_end", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+            res = (ms.value, n.value, fl.value)
+        return max_over_ranks(el), res
+
+    def fwd_step():
+        with torch.no_grad():
+            return model(img, cam_label=cam, training=False)
+
+    ts = None
+    if args.workload == "train":
         from signal_amd.engine.trainer import TrainStep
         ts = TrainStep(cfg, model, num_classes=171, world_size=world)
 
         def step():
             return ts.step(img, vid, cam)
-        parallelism = f"dp{world} (RCCL all-reduce of gradients overlapped with backward)"
+        parallelism = (f"dp{world} (RCCL all-reduce of gradients, one 28 MB bucket per transformer block issued from the "
+                       "backward, overlapped with the blocks below)") if world > 1 else "dp1 (single GPU, no collective)"
+        if world > 1 and args.backend != "nccl":
+            parallelism = parallelism.replace("RCCL", args.backend + " (test backend)")
+        # dominant kernel of the train step by total time (profiles/r02_train_*): the weight-gradient GEMM
+        prof = (PROF_TN256, 0, 0)
+        kname = "gemm_tn256_kernel (weight gradients dW = dY^T X of qkv / out_proj / c_fc / c_proj, M=%d rows)" % M
+        kkey = "gemm_tn256_kernel"
+    else:
+        step = fwd_step
+        parallelism = f"dp{world} (independent shards, no collective)"
+        prof = (ops.BIAS_GELU_BF16, Fd, D)
+        kname = "gemm_nt256_kernel<BIAS_GELU> (c_fc, M=%d N=%d K=%d)" % (M, Fd, D)
+        kkey = "gemm_nt256_kernel<5>"
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    el, (pms, pn, pfl) = timed(step, args.steps, args.warmup, prof)
+    ach = pfl / (pms * 1e-3) / 1e12 if pn else 0.0
+    traffic, tsrc = committed_traffic(kkey)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    D, Fd = model.hip.D, model.hip.F
-    _lib.call("sig_prof_begin", ops.BIAS_GELU_BF16, Fd, D, 12 * args.steps + 8)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    el = time.perf_counter() - t0
-    ms, n, fl = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-    _lib.call("sig_prof_end", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+    fwd = None
+    if args.workload == "train" and not args.no_fwd_sim:
+        fel, (fms, fn, ffl) = timed(fwd_step, args.steps, min(args.warmup, 2), (ops.BIAS_GELU_BF16, Fd, D))
+        fach = ffl / (fms * 1e-3) / 1e12 if fn else 0.0
+        fwd = {"workload": "configs[1]: three-stream ViT-B/16 forward + SIM, no grad, no collective",
+               "value": round(world * B * args.steps / fel, 2), "unit": "triplets/s", "ms_per_step": round(fel / args.steps * 1e3, 3),
+               "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<BIAS_GELU> (c_fc, M=%d N=%d K=%d)" % (M, Fd, D),
+                            "achieved": round(fach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(fach / PEAK_MFMA_TFLOPS, 4), "launches": fn, "avg_us": round(fms / max(fn, 1) * 1e3, 2)}}
 
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
     if rank != 0:
         if world > 1:
-            torch.distributed.destroy_process_group()
+            dist.destroy_process_group()
         return
 
-    ach = fl.value / (ms.value * 1e-3) / 1e12 if n.value else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("gemm_nt_c_fc_bytes_per_launch")
     out = {
         "metric": "images/sec (RGB+NIR+TIR triplets) at B=64/GPU",
         "value": round(world * B * args.steps / el, 2), "unit": "triplets/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": {"fwd_sim": "configs[1]: three-stream ViT-B/16 forward + SIM, RGBNT201 256x128, random init",
-                                "train": "configs[2]: full Signal (SIM+GAM+LAM) train step, RGBNT201 256x128, random init"}[args.workload],
+                                "train": "configs[%d]: full Signal (SIM+GAM+LAM) train step incl. fused Adam, RGBNT201 256x128, random init"
+                                % (2 if world == 1 else 3)}[args.workload],
                    "batch_per_gpu": B, "global_batch": B * world, "tokens_per_image": 129, "parallelism": parallelism},
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<BIAS_GELU_BF16> (c_fc, M=%d N=%d K=%d)" % (3 * B * 129, Fd, D),
-                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                     "launches": n.value, "avg_us": round(ms.value / max(n.value, 1) * 1e3, 2)},
+        "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                     "launches": pn, "avg_us": round(pms / max(pn, 1) * 1e3, 2)},
     }
+    if ts is not None and getattr(ts, "scaler", None) is not None:
+        out["config"]["loss_scale"] = ts.scaler.describe()
+    if fwd is not None:
+        out["fwd_sim"] = fwd
     if args.h2d and world == 1:
         from signal_amd.data import DevicePrefetcher
         host = [({k: v.cpu().pin_memory() for k, v in img.items()}, vid.cpu(), cam.cpu(), torch.zeros(B, dtype=torch.int64), None)
@@ -201,7 +285,7 @@ def main():
 
         def run():
             for b_img, b_vid, b_cam, _, _ in DevicePrefetcher((host[i & 1] for i in range(n)), dev):
-                if args.workload == "fwd_sim":
+                if ts is None:
                     with torch.no_grad():
                         model(b_img, cam_label=b_cam, training=False)
                 else:
@@ -218,7 +302,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.workload)
     print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.destroy_process_group()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -8,7 +8,10 @@
  *   - every pointer is a DEVICE pointer the caller owns (PyTorch caching allocator); the library borrows
  *     it for the duration of the call, keeps no reference and never allocates, frees or synchronises;
  *   - `stream` is a hipStream_t passed as void* (the caller's current stream); calls are re-entrant;
- *   - bf16 tensors are raw uint16_t bit patterns; "rows padded" means the allocation holds
+ *   - 16-bit tensors are raw uint16_t bit patterns of ONE operand type per model, chosen by `dtype`:
+ *     SIG_DT_BF16 (bfloat16) or SIG_DT_F16 (IEEE half, the type the reference's CUDA autocast computes in,
+ *     engine/processor.py:165); both run the same MFMA rate, accumulation / residual stream / LayerNorm / softmax
+ *     are f32 either way.  Names that say "bf16" mean "the 16-bit operand type"; "rows padded" means the allocation holds
  *     ceil(rows/128)*128 rows and the pad rows are zero (the library never writes them);
  *   - return 0 on success; non-zero = argument (1) or launch (2) error, message via sig_last_error().
  */
@@ -21,7 +24,9 @@
 extern "C" {
 #endif
 
-#define SIG_ABI_VERSION 1
+#define SIG_ABI_VERSION 2
+
+enum { SIG_DT_BF16 = 0, SIG_DT_F16 = 1 };
 
 const char* sig_last_error(void);
 int sig_version(void);
@@ -29,7 +34,9 @@ int sig_version(void);
 /* Measurement aid (bench.py roofline leg): bracket every sig_gemm_nt launch of ONE shape (epilogue, N, K)
  * with HIP events on its own stream, from sig_prof_begin until sig_prof_end; sig_prof_end waits for the
  * recorded events (host-synchronising: call it outside any timed region) and returns the summed kernel
- * time, the number of launches and their algorithmic FLOPs (2*M*N*K each). */
+ * time, the number of launches and their algorithmic FLOPs (2*M*N*K each).  epilogue = SIG_PROF_TN256 selects
+ * the 256x256 weight-gradient kernel behind sig_gemm_tn instead (N = I, K = J; N = K = 0: every shape). */
+#define SIG_PROF_TN256 100
 int sig_prof_begin(int epilogue, int N, int K, int max_launches);
 int sig_prof_end(double* total_ms, int* launches, double* flops);
 
@@ -52,51 +59,51 @@ enum {
  * their input gradients (Bt = the transposed weight).  A rows padded; N % 128 == 0, K % 64 == 0. */
 int sig_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, int epilogue,
                 void* out, int ldo, const float* bias, const float* res, int ldr, void* aux, int ldaux,
-                void* stream);
+                int dtype, void* stream);
 
 /* out[I,J] += P[Mr,I]^T * Q[Mr,J]  (f32, atomically accumulated): weight gradients dW = dY^T X that autograd
  * computes for the same layers.  Mr % 64 == 0 with zero pad rows; I, J % 128 == 0; split = 0 lets the
  * library choose the number of row chunks. */
 int sig_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, int Mr, int I, int J, float* out,
-                int ldo, int split, void* stream);
+                int ldo, int split, int dtype, void* stream);
 
 /* LayerNorm (fp32 statistics, eps as given): modeling/clip/model.py:154-160, AddModule/useA.py:414-423.
  * y_bf16 / y_f32 / mean / rstd may be NULL when not wanted. */
 int sig_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y_bf16, float* y_f32,
-                      float* mean, float* rstd, int M, int D, float eps, void* stream);
+                      float* mean, float* rstd, int M, int D, float eps, int dtype, void* stream);
 /* dx = dres + LN'(dy); dgamma/dbeta are ACCUMULATED (atomics) and may both be NULL. */
 int sig_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                       const float* rstd, const float* dres, float* dx_f32, uint16_t* dx_bf16, float* dgamma,
-                      float* dbeta, int M, int D, void* stream);
+                      float* dbeta, int M, int D, int dtype, void* stream);
 
 /* Self-attention of nn.MultiheadAttention as called at modeling/clip/model.py:223-225 (no mask, no dropout):
  * qkv bf16 [S*L, 3*H*64] packed (q|k|v, head h = columns 64h..64h+63 of each) -> out bf16 [S*L, H*64],
  * lse f32 [S,H,L] (log-sum-exp of the scaled scores, kept for backward).  L <= 144. */
-int sig_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int S, int L, int H, void* stream);
+int sig_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int S, int L, int H, int dtype, void* stream);
 int sig_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
-                 uint16_t* dqkv, int S, int L, int H, void* stream);
+                 uint16_t* dqkv, int S, int L, int H, int dtype, void* stream);
 
 /* Packing helpers: f32 -> bf16 (optionally transposed), column sums (bias gradients, accumulated). */
-int sig_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
-int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, void* stream);
+int sig_cast_bf16(const float* src, uint16_t* dst, size_t n, int dtype, void* stream);
+int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int dtype, void* stream);
 /* n transposes in one launch: table[d] = {src f32*, dst bf16*, rows, cols} as int64, tile_start[d] = index of matrix d's
  * first 64x64 tile in the flattened grid, tile_start[n] = total_tiles. */
-int sig_transpose_cast_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, void* stream);
-int sig_colsum_bf16(const uint16_t* a, int lda, int M, int N, float* out, void* stream);
+int sig_transpose_cast_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, int dtype, void* stream);
+int sig_colsum_bf16(const uint16_t* a, int lda, int M, int N, float* out, int dtype, void* stream);
 int sig_colsum_f32(const float* a, int lda, int M, int N, float* out, void* stream);
 
 /* Patch embedding front end (modeling/clip/model.py:448-459; modeling/meta_arch.py:101-103).
  * sig_im2col: img f32 [nimg,3,H,W] -> bf16 [nimg*(H/P)*(W/P), 3*P*P] (column = c*P*P + dy*P + dx), the A
  * operand of the conv1-as-GEMM.  sig_embed_assemble: prepend class_embedding, add sie_coe*cv_embed[cam[b]] to
  * the CLS row, add positional_embedding, apply ln_pre.  Sequences are ordered s = modality*B + b. */
-int sig_im2col(const float* img, uint16_t* out, int nimg, int H, int W, int P, void* stream);
+int sig_im2col(const float* img, uint16_t* out, int nimg, int H, int W, int P, int dtype, void* stream);
 int sig_embed_assemble(const float* tok, const float* class_embedding, const float* positional_embedding,
                        const float* cv_embed, const int64_t* cam_label, float sie_coe, const float* ln_w,
                        const float* ln_b, float* x, float* pre_ln, float* mean, float* rstd, int S, int B, int L,
                        int D, float eps, void* stream);
 int sig_embed_assemble_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dtok_bf16, float* d_class_embedding,
                   float* d_positional_embedding, float* d_cv_embed, const int64_t* cam_label, float sie_coe,
-                  int S, int B, int L, int D, void* stream);
+                  int S, int B, int L, int D, int dtype, void* stream);
 
 /* ================================================================================================
  * Stage-level entry points: one call per stage of VisionTransformer.forward (modeling/clip/model.py:447-488)
@@ -107,6 +114,7 @@ int sig_embed_assemble_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dto
  * ================================================================================================ */
 typedef struct SigVitDims {
     int S, B, L, D, H, F, out_dim;   /* sequences, per-modality batch, tokens, width, heads, MLP width, proj columns */
+    int dtype;                       /* SIG_DT_BF16 / SIG_DT_F16: type of every 16-bit activation and weight operand */
 } SigVitDims;
 
 /* --- patch embedding + CLS/camera/positional + ln_pre (clip/model.py:448-459, meta_arch.py:101-103) --- */
@@ -198,6 +206,7 @@ typedef struct SigSimParams {
     const uint16_t *wt_q, *wt_kv, *wt_o, *wt_f1, *wt_f2;     /* transposes, backward only */
     const float *b_q, *b_kv, *b_o, *b_f1, *b_f2, *n1_w, *n1_b, *n2_w, *n2_b;
     int topk;                                                /* MODEL.TOPK: k1 = topk, k2 = 2*topk */
+    int dtype;                                               /* SIG_DT_BF16 / SIG_DT_F16 (selection itself is f32) */
 } SigSimParams;
 typedef struct SigSimActs {
     float *qprime, *cconst, *intra, *inter;  /* [B,3,512] [B,3] [B,3,Lp] [B,3,3Lp] : selection scores (raw, pre-softmax) */
@@ -234,9 +243,9 @@ int sig_sim_fwd(const float* tokens, int B, int L, const SigSimParams* p, const 
 int sig_sim_bwd(const float* dout, int B, int L, const SigSimParams* p, const SigSimActs* a, const SigSimGrads* g,
                 const SigSimScratch* s, float* dtokens, void* stream);
 /* attention core of the interaction block, exposed for tests */
-int sig_xattn_fwd(const float* q, const uint16_t* kv, int B, int NK, uint16_t* out, float* probs, void* stream);
+int sig_xattn_fwd(const float* q, const uint16_t* kv, int B, int NK, uint16_t* out, float* probs, int dtype, void* stream);
 int sig_xattn_bwd(const float* q, const uint16_t* kv, const float* probs, const float* dout, int B, int NK, float* dq,
-                  uint16_t* dkv, void* stream);
+                  uint16_t* dkv, int dtype, void* stream);
 
 /* ================================================================================================
  * GAM -- AlignmentM.Cls_Align (modeling/AddModule/useB.py:76-126) with volume_computation3
@@ -274,8 +283,9 @@ typedef struct SigLamActs {         /* leading [3] = modality; R = B*(L-1) rows 
     float* loss;                    /* [1] */
 } SigLamActs;
 typedef struct SigLamScratch { uint16_t *da1pre, *dq; float* dx; } SigLamScratch;   /* [R,512] each, pad rows zero */
-int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, const SigDasParams* p3, const SigLamActs* a, void* stream);
-int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, const SigDasParams* p3, const SigDasGrads* g3,
+int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, int dtype, const SigDasParams* p3, const SigLamActs* a,
+                void* stream);
+int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, int dtype, const SigDasParams* p3, const SigDasGrads* g3,
                 const SigLamActs* a, const SigLamScratch* s, const float* dloss, float* dtokens, void* stream);
 
 /* ================================================================================================
@@ -283,12 +293,22 @@ int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, const SigDasPar
  * torch.optim.Adam semantics (L2 weight decay added to the gradient, bias correction, eps outside the sqrt)
  * over a flat f32 parameter buffer cut into nseg segments (one per parameter, the reference's one param
  * group per parameter) with per-segment lr and weight decay.  seg_end[k] = end offset (elements) of segment
- * k; grad_scale multiplies the gradient first (1/world_size after a sum all-reduce); p_bf16 (may be NULL)
- * receives the refreshed bf16 GEMM operands.
+ * k; grad_scale multiplies the gradient first (1/world_size after a sum all-reduce); p16 (may be NULL)
+ * receives the refreshed 16-bit GEMM operands of type `dtype`.
+ *
+ * fp16 loss scaling = the reference's amp.GradScaler (processor.py:119,259-261) kept on the device:
+ * scale_state (NULL = no scaling) is a 5-float record [scale, 1/scale, found_inf, growth_tracker, applied_steps].
+ *   sig_grad_check         found_inf = 1 if any gradient element is inf / NaN
+ *   sig_adam_step          multiplies gradients by 1/scale, skips the WHOLE update when found_inf is set and takes
+ *                          the bias-correction step from applied_steps + 1 (the `step` argument is then ignored)
+ *   sig_loss_scale_update  scale *= backoff after an overflow, *= growth after `interval` clean steps; clears
+ *                          found_inf; counts applied steps.  No call synchronises with the host.
  * ================================================================================================ */
-int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, const int* seg_end,
+int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p16, int dtype, const int* seg_end,
                   const float* seg_lr, const float* seg_wd, int nseg, float beta1, float beta2, float eps, int step,
-                  float grad_scale, size_t n, void* stream);
+                  float grad_scale, const float* scale_state, size_t n, void* stream);
+int sig_grad_check(const float* g, size_t n, float* scale_state, void* stream);
+int sig_loss_scale_update(float* scale_state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 /* ================================================================================================
  * ReID head.  All f32, B <= 128.

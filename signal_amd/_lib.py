@@ -15,20 +15,20 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "sig_prof_begin": [_i, _i, _i, _i],
     "sig_prof_end": [_vp, _vp, _vp],
-    "sig_gemm_nt": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp],
-    "sig_gemm_tn": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
-    "sig_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
-    "sig_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "sig_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
-    "sig_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "sig_cast_bf16": [_vp, _vp, _sz, _vp],
-    "sig_transpose_cast_bf16": [_vp, _vp, _i, _i, _vp],
-    "sig_transpose_cast_multi": [_vp, _vp, _i, _i, _vp],
-    "sig_colsum_bf16": [_vp, _i, _i, _i, _vp, _vp],
+    "sig_gemm_nt": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "sig_gemm_tn": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "sig_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "sig_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sig_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sig_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sig_cast_bf16": [_vp, _vp, _sz, _i, _vp],
+    "sig_transpose_cast_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "sig_transpose_cast_multi": [_vp, _vp, _i, _i, _i, _vp],
+    "sig_colsum_bf16": [_vp, _i, _i, _i, _vp, _i, _vp],
     "sig_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
-    "sig_im2col": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "sig_im2col": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sig_embed_assemble": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
-    "sig_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp],
+    "sig_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp],
 }
 
 
@@ -40,7 +40,7 @@ def _struct(name, ptr_fields, tail=()):
 
 
 class SigVitDims(C.Structure):
-    _fields_ = [(n, _i) for n in ("S", "B", "L", "D", "H", "F", "out_dim")]
+    _fields_ = [(n, _i) for n in ("S", "B", "L", "D", "H", "F", "out_dim", "dtype")]
 
 
 SigEmbedParams = _struct("SigEmbedParams", ["w_conv", "class_embedding", "positional_embedding", "cv_embed", "ln_w", "ln_b"],
@@ -59,7 +59,7 @@ SigHeadActs = _struct("SigHeadActs", ["x", "hp", "mean", "rstd", "tokens"])
 SigHeadGrads = _struct("SigHeadGrads", ["proj", "ln_w", "ln_b"])
 SigSimParams = _struct("SigSimParams", ["sel_wq", "sel_bq", "sel_wk", "sel_bk", "w_q", "w_kv", "w_o", "w_f1", "w_f2",
                                          "wt_q", "wt_kv", "wt_o", "wt_f1", "wt_f2", "b_q", "b_kv", "b_o", "b_f1", "b_f2",
-                                         "n1_w", "n1_b", "n2_w", "n2_b"], [("topk", _i)])
+                                         "n1_w", "n1_b", "n2_w", "n2_b"], [("topk", _i), ("dtype", _i)])
 SigSimActs = _struct("SigSimActs", ["qprime", "cconst", "intra", "inter", "mask_f", "mask_u8", "sel", "cls_b", "cls_f", "qh",
                                      "kv", "probs", "ao", "y", "z1", "z1_b", "mean1", "rstd1", "f1_pre", "f1", "y2", "mean2",
                                      "rstd2", "out"])
@@ -77,11 +77,13 @@ SIGNATURES.update({
     "sig_bnneck_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sig_bnneck_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sig_reid_loss": [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sig_adam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _f, _sz, _vp],
+    "sig_adam_step": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _i, _f, _vp, _sz, _vp],
+    "sig_grad_check": [_vp, _sz, _vp, _vp],
+    "sig_loss_scale_update": [_vp, _f, _f, _i, _vp],
     "sig_gam_fwd": [_vp, _i, _i, _vp, _vp, _vp],
     "sig_gam_bwd": [_i, _i, _vp, _vp, _vp, _vp, _vp],
-    "sig_lam_fwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
-    "sig_lam_bwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sig_lam_fwd": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "sig_lam_bwd": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sig_embed_assemble_bwd": SIGNATURES.pop("sig_embed_bwd"),
     "sig_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sig_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
@@ -92,8 +94,8 @@ SIGNATURES.update({
     "sig_sim_select": [_vp, _i, _i, _vp, _vp, _vp],
     "sig_sim_fwd": [_vp, _i, _i, _vp, _vp, _vp],
     "sig_sim_bwd": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sig_xattn_fwd": [_vp, _vp, _i, _i, _vp, _vp, _vp],
-    "sig_xattn_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "sig_xattn_fwd": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp],
+    "sig_xattn_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
 })
 
 

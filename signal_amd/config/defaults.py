@@ -106,7 +106,10 @@ def get_cfg_defaults() -> CfgNode:
                    DIST_TRAIN=False, PROMPT=False, ADAPTER=False, FROZEN=False, IF_LABELSMOOTH="on", DIRECT=1,
                    DROP_PATH=0.1, DROP_OUT=0.0, ATT_DROP_RATE=0.0, TRANSFORMER_TYPE="vit_base_patch16_224",
                    STRIDE_SIZE=[16, 16], USE_A=False, USE_B=False, TOPK=64, FIXED_KEEP_RATIO=False, KEEP_RATIO=0.75,
-                   stageName="CLS ", SIE_COE=3.0, SIE_CAMERA=True, SIE_VIEW=False, NO_MARGIN=True),
+                   stageName="CLS ", SIE_COE=3.0, SIE_CAMERA=True, SIE_VIEW=False, NO_MARGIN=True,
+                   # signal_amd only (not a reference key): MFMA operand type, "bf16" or "fp16" (fp16 = the type of the
+                   # reference's CUDA autocast; trained with device-side dynamic loss scaling)
+                   OPERAND_DTYPE="bf16"),
         INPUT=dict(SIZE_TRAIN=[256, 128], SIZE_TEST=[256, 128], PROB=0.5, RE_PROB=0.5, PIXEL_MEAN=[0.5, 0.5, 0.5],
                    PIXEL_STD=[0.5, 0.5, 0.5], PADDING=10),
         DATASETS=dict(NAMES="RGBNT201", ROOT_DIR="./data"),

@@ -211,7 +211,7 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
 
 // xb[m][b*Lp + j][:] = bf16(patch j of (m,b));  modality stride = xstride rows
 __global__ __launch_bounds__(256) void lam_gather_kernel(const float* __restrict__ tokens, int L, int B, bf16_t* __restrict__ xb,
-                                                         size_t xstride) {
+                                                         size_t xstride, int dt) {
     const int Lp = L - 1, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= 3 * B * Lp) return;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void lam_gather_kernel(const float* __restrict
     const float* t = tokens + ((size_t)s * L + 1 + j) * AL_D + lane * 8;
     const float4 a = *(const float4*)t, c = *(const float4*)(t + 4);
     *(uint4*)(xb + ((size_t)m * xstride + (size_t)b * Lp + j) * AL_D + lane * 8) =
-        make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(c.x, c.y), pack2bf(c.z, c.w));
+        make_uint4(pack2_16(a.x, a.y, dt), pack2_16(a.z, a.w, dt), pack2_16(c.x, c.y, dt), pack2_16(c.z, c.w, dt));
 }
 
 // dtokens[patch rows of modality m] += src[(b*Lp + j)][:]   (f32)
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void lam_tail_fwd_kernel(const float* __restri
                                                            const bf16_t* __restrict__ a1, const float* __restrict__ wd,
                                                            const float* __restrict__ bd, const float* __restrict__ w4,
                                                            float* __restrict__ a2pre, float* __restrict__ offs,
-                                                           float* __restrict__ samp) {
+                                                           float* __restrict__ samp, int dt) {
     __shared__ float red[8][8];
     __shared__ float pos[8][2];
     const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void lam_tail_fwd_kernel(const float* __restri
 #pragma unroll
                 for (int dx = 0; dx < 4; ++dx) {
                     const int tok = (4 * hk + dy) * g.w + 4 * wk + dx;
-                    acc += wdc[dy * 4 + dx] * bf2f(a1[((size_t)b * Lp + tok) * AL_D + c]);
+                    acc += wdc[dy * 4 + dx] * cvt16f(a1[((size_t)b * Lp + tok) * AL_D + c], dt);
                 }
             a2pre[((size_t)b * P + p) * AL_D + c] = acc;
             part[p] = w4c * gelu_erf(acc);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void lam_tail_bwd_kernel(const float* __restri
                                                            const float* __restrict__ samp_all, size_t nsamp,
                                                            const float* __restrict__ dloss, bf16_t* __restrict__ da1pre,
                                                            float* __restrict__ dwd, float* __restrict__ dbd, float* __restrict__ dw4,
-                                                           float* __restrict__ dtokens, float* __restrict__ part) {
+                                                           float* __restrict__ dtokens, float* __restrict__ part, int dt) {
     __shared__ float red[8][16];
     __shared__ float dofs[8];
     const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
@@ -415,9 +415,9 @@ __global__ __launch_bounds__(512) void lam_tail_bwd_kernel(const float* __restri
 #pragma unroll
             for (int dxx = 0; dxx < 4; ++dxx) {
                 const size_t row = (size_t)b * Lp + (4 * hk + dy) * g.w + 4 * wk + dxx;
-                dwdc[dy * 4 + dxx] += dpre * bf2f(a1[row * AL_D + c]);
+                dwdc[dy * 4 + dxx] += dpre * cvt16f(a1[row * AL_D + c], dt);
                 const float da1 = dpre * wd[c * 16 + dy * 4 + dxx];
-                da1pre[row * AL_D + c] = f2bf(da1 * gelu_erf_grad(bf2f(a1pre[row * AL_D + c])));
+                da1pre[row * AL_D + c] = f2cvt16(da1 * gelu_erf_grad(cvt16f(a1pre[row * AL_D + c], dt)), dt);
             }
     }
     // Parameter gradients: one partial row per sample, [B][18 * 512] = (dwd[512*16] | dbd[512] | dw4[512]), summed by
@@ -447,9 +447,10 @@ __global__ __launch_bounds__(256) void lam_tail_reduce_kernel(const float* __res
     *dst += a;
 }
 
-int sig_launch_lam_gather(const float* tokens, int B, int L, bf16_t* xb, size_t xstride, hipStream_t st) {
+int sig_launch_lam_gather(const float* tokens, int B, int L, bf16_t* xb, size_t xstride, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "lam_gather");
     SIG_CHECK_ARG(tokens && xb && B > 0 && L > 1, "lam_gather: bad arguments");
-    hipLaunchKernelGGL(lam_gather_kernel, dim3(sig_ceil_div(3 * B * (L - 1), 4)), dim3(256), 0, st, tokens, L, B, xb, xstride);
+    hipLaunchKernelGGL(lam_gather_kernel, dim3(sig_ceil_div(3 * B * (L - 1), 4)), dim3(256), 0, st, tokens, L, B, xb, xstride, dt);
     SIG_CHECK_LAUNCH("lam_gather");
     return 0;
 }
@@ -466,11 +467,12 @@ static int lam_geom(int h, int w, LamGeom* g) {
     return 0;
 }
 int sig_launch_lam_tail_fwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const float* wd,
-                            const float* bd, const float* w4, float* a2pre, float* offs, float* samp, hipStream_t st) {
+                            const float* bd, const float* w4, float* a2pre, float* offs, float* samp, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "lam_tail_fwd");
     LamGeom g;
     if (int rc = lam_geom(h, w, &g)) return rc;
     SIG_CHECK_ARG(h * w == L - 1, "lam: grid %dx%d does not match %d patches", h, w, L - 1);
-    hipLaunchKernelGGL(lam_tail_fwd_kernel, dim3(B), dim3(512), 0, st, tokens, m, L, B, g, a1, wd, bd, w4, a2pre, offs, samp);
+    hipLaunchKernelGGL(lam_tail_fwd_kernel, dim3(B), dim3(512), 0, st, tokens, m, L, B, g, a1, wd, bd, w4, a2pre, offs, samp, dt);
     SIG_CHECK_LAUNCH("lam_tail_fwd");
     return 0;
 }
@@ -486,12 +488,13 @@ int sig_launch_lam_loss(const float* samp, size_t n, float* loss, hipStream_t st
 int sig_launch_lam_tail_bwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre,
                             const float* wd, const float* w4, const float* a2pre, const float* offs, const float* samp_all,
                             size_t nsamp, const float* dloss, bf16_t* da1pre, float* dwd, float* dbd, float* dw4, float* dtokens,
-                            hipStream_t st, float* partials) {
+                            int dt, hipStream_t st, float* partials) {
+    SIG_CHECK_DT(dt, "lam_tail_bwd");
     LamGeom g;
     if (int rc = lam_geom(h, w, &g)) return rc;
     // partials: caller scratch of >= B * 18 * 512 floats (nullptr -> contended atomics straight into the gradients)
     hipLaunchKernelGGL(lam_tail_bwd_kernel, dim3(B), dim3(512), 0, st, tokens, m, L, B, g, a1, a1pre, wd, w4, a2pre, offs, samp_all,
-                       nsamp, dloss, da1pre, dwd, dbd, dw4, dtokens, partials);
+                       nsamp, dloss, da1pre, dwd, dbd, dw4, dtokens, partials, dt);
     SIG_CHECK_LAUNCH("lam_tail_bwd");
     if (partials) {
         hipLaunchKernelGGL(lam_tail_reduce_kernel, dim3(sig_ceil_div(18 * AL_D, 256)), dim3(256), 0, st, partials, B, dwd, dbd, dw4);

@@ -30,7 +30,7 @@ __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((
 
 // FULL: L in (128, 144], i.e. all nine 16-row tiles exist (every shipped config: L = 129) -- the per-tile guards fold away;
 // with a run-time tile count the ~50 live scalar conditions were spilled to VGPR lanes (v_writelane / v_readlane).
-template <bool FULL>
+template <bool FULL, int DT>
 __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int S, int L, int H) {
     __shared__ __attribute__((aligned(16))) char smem[ATT_KROWS * 128 + ATT_VROWS * 128];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(kt * 16 + fr, (ks << 2) | g));
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);
+                    a = mfma16<DT>(kf, qf[ks], a);
                 }
                 if (kt * 16 + 16 > L) {   // uniform: the tile that straddles L
 #pragma unroll
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restri
             if (!FULL && kk * 2 >= NT) break;
             const f32x4_t p0 = sc[2 * kk], p1 = sc[2 * kk + 1];
             union { uint32_t w[4]; bf16x8_t v; } pk;
-            pk.w[0] = pack2bf(p0[0], p0[1]); pk.w[1] = pack2bf(p0[2], p0[3]);
-            pk.w[2] = pack2bf(p1[0], p1[1]); pk.w[3] = pack2bf(p1[2], p1[3]);
+            pk.w[0] = pack2_t<DT>(p0[0], p0[1]); pk.w[1] = pack2_t<DT>(p0[2], p0[3]);
+            pk.w[2] = pack2_t<DT>(p1[0], p1[1]); pk.w[3] = pack2_t<DT>(p1[2], p1[3]);
             const bf16x8_t pf = pk.v;
             const int r0 = 32 * kk + 4 * g + tq;
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restri
                 const bf16x4_t v0 = lds_tr16(sV + v_off(r0, chunk) + ((tp & 1) << 3));
                 const bf16x4_t v1 = lds_tr16(sV + v_off(r0 + 16, chunk) + ((tp & 1) << 3));
                 const bf16x8_t vf = (bf16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+                o[dt] = mfma16<DT>(vf, pf, o[dt]);
             }
         }
         // lane (fr, g) holds head columns dt*16 + 4g .. +3 of query fr: exchange lane pairs g / g^1 (v_permlane16_swap, as
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restri
             uint32_t w[4][2];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                w[dt][0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
-                w[dt][1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+                w[dt][0] = pack2_t<DT>(o[dt][0] * inv, o[dt][1] * inv);
+                w[dt][1] = pack2_t<DT>(o[dt][2] * inv, o[dt][3] * inv);
             }
 #pragma unroll
             for (int dp = 0; dp < 2; ++dp) {
@@ -187,11 +187,17 @@ __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restri
 #endif
 }
 
-int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, hipStream_t st) {
+template <int DT>
+static void launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, hipStream_t st) {
+    if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL((attn_fwd_kernel<true, DT>), dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, DT>), dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
+}
+int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "attn_fwd");
     SIG_CHECK_ARG(qkv && out, "attn_fwd: null pointer");
     SIG_CHECK_ARG(S > 0 && H > 0 && L > 0 && L <= ATT_KROWS, "attn_fwd: L=%d must be in 1..%d", L, ATT_KROWS);
-    if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
+    if (dt == SIG_DT_F16) launch_attn_fwd<SIG_DT_F16>(qkv, out, lse, S, L, H, st);
+    else launch_attn_fwd<SIG_DT_BF16>(qkv, out, lse, S, L, H, st);
     SIG_CHECK_LAUNCH("attn_fwd");
     return 0;
 }
@@ -218,12 +224,13 @@ __device__ __forceinline__ int d_off(int row, int chunk) {
 // Store a 16-row x 64-column f32 accumulator tile (lane (fr, g): columns dt*16 + 4g .. +3 of row fr) as bf16 with
 // 16-B stores: lanes g / g^1 exchange halves (v_permlane16_swap, see gemm_bf16.hip) so a lane owns 8 consecutive columns.
 // `row` = this lane's row base (64 columns), `live` = the row exists; every lane must call it (the swap needs all).
+template <int DT>
 __device__ __forceinline__ void store_rows16(const f32x4_t (&o)[4], bf16_t* row, bool live, int g) {
     uint32_t w[4][2];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-        w[dt][0] = pack2bf(o[dt][0], o[dt][1]);
-        w[dt][1] = pack2bf(o[dt][2], o[dt][3]);
+        w[dt][0] = pack2_t<DT>(o[dt][0], o[dt][1]);
+        w[dt][1] = pack2_t<DT>(o[dt][2], o[dt][3]);
     }
 #pragma unroll
     for (int dp = 0; dp < 2; ++dp) {
@@ -234,7 +241,7 @@ __device__ __forceinline__ void store_rows16(const f32x4_t (&o)[4], bf16_t* row,
 }
 
 #define ATB_ROWS 144  // 9 tiles; reads past it are clamped (they only ever meet zero probabilities)
-template <bool FULL>
+template <bool FULL, int DT>
 __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                        bf16_t* __restrict__ dqkv, int S, int L, int H) {
@@ -289,8 +296,8 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            d += bf2f((bf16_t)(gw[e] & 0xffff)) * bf2f((bf16_t)(ow[e] & 0xffff));
-            d += bf2f((bf16_t)(gw[e] >> 16)) * bf2f((bf16_t)(ow[e] >> 16));
+            d += cvt16f_t<DT>((bf16_t)(gw[e] & 0xffff)) * cvt16f_t<DT>((bf16_t)(ow[e] & 0xffff));
+            d += cvt16f_t<DT>((bf16_t)(gw[e] >> 16)) * cvt16f_t<DT>((bf16_t)(ow[e] >> 16));
         }
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
@@ -335,8 +342,8 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8_t kf = *(const bf16x8_t*)(sK + d_off(kt * 16 + fr, (ks << 2) | g));
                     const bf16x8_t vf = *(const bf16x8_t*)(sV + d_off(kt * 16 + fr, (ks << 2) | g));
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);  // S^T
-                    b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], b, 0, 0, 0);  // dP^T
+                    a = mfma16<DT>(kf, qf[ks], a);  // S^T
+                    b = mfma16<DT>(vf, gf[ks], b);  // dP^T
                 }
             }
 #pragma unroll
@@ -361,8 +368,8 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
             if (!FULL && kk * 2 >= NT) break;
             const f32x4_t p0 = ds[2 * kk], p1 = ds[2 * kk + 1];
             union { uint32_t w[4]; bf16x8_t v; } pk;
-            pk.w[0] = pack2bf(p0[0], p0[1]); pk.w[1] = pack2bf(p0[2], p0[3]);
-            pk.w[2] = pack2bf(p1[0], p1[1]); pk.w[3] = pack2bf(p1[2], p1[3]);
+            pk.w[0] = pack2_t<DT>(p0[0], p0[1]); pk.w[1] = pack2_t<DT>(p0[2], p0[3]);
+            pk.w[2] = pack2_t<DT>(p1[0], p1[1]); pk.w[3] = pack2_t<DT>(p1[2], p1[3]);
             const bf16x8_t pf = pk.v;
             const int r0 = 32 * kk + 4 * g + tq;
             const int r1 = r0 + 16 < ATB_ROWS ? r0 + 16 : r0;  // tile 9 does not exist: its dS is 0
@@ -372,10 +379,10 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
                 const bf16x4_t v0 = lds_tr16(sK + d_off(r0, chunk) + ((tp & 1) << 3));
                 const bf16x4_t v1 = lds_tr16(sK + d_off(r1, chunk) + ((tp & 1) << 3));
                 const bf16x8_t kf = (bf16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, pf, o[dt], 0, 0, 0);
+                o[dt] = mfma16<DT>(kf, pf, o[dt]);
             }
         }
-        store_rows16(o, dqkv + ((size_t)s * L + (q < L ? q : 0)) * D3 + h * 64, q < L, g);
+        store_rows16<DT>(o, dqkv + ((size_t)s * L + (q < L ? q : 0)) * D3 + h * 64, q < L, g);
     }
 
 #ifdef SIG_ATTN_STAMPS
@@ -415,8 +422,8 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
                     for (int ks = 0; ks < 2; ++ks) {
                         const bf16x8_t qf = *(const bf16x8_t*)(sQ + d_off(qt * 16 + fr, (ks << 2) | g));
                         const bf16x8_t gf = *(const bf16x8_t*)(sG + d_off(qt * 16 + fr, (ks << 2) | g));
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], a, 0, 0, 0);  // S  [row q][col key]
-                        b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf[ks], b, 0, 0, 0);  // dP [row q][col key]
+                        a = mfma16<DT>(qf, kf[ks], a);  // S  [row q][col key]
+                        b = mfma16<DT>(gf, vf[ks], b);  // dP [row q][col key]
                     }
                 }
                 // 4 consecutive queries per lane: their pre-scaled lse / delta in one b128 read each (+inf / 0 past L)
@@ -427,8 +434,8 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
                     pv[e] = keyok ? __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -l4[e])) : 0.f;
                     dsv[e] = pv[e] * __builtin_fmaf(b[e], scale, -d4[e]);
                 }
-                pw[half * 2] = pack2bf(pv[0], pv[1]); pw[half * 2 + 1] = pack2bf(pv[2], pv[3]);
-                sw[half * 2] = pack2bf(dsv[0], dsv[1]); sw[half * 2 + 1] = pack2bf(dsv[2], dsv[3]);
+                pw[half * 2] = pack2_t<DT>(pv[0], pv[1]); pw[half * 2 + 1] = pack2_t<DT>(pv[2], pv[3]);
+                sw[half * 2] = pack2_t<DT>(dsv[0], dsv[1]); sw[half * 2 + 1] = pack2_t<DT>(dsv[2], dsv[3]);
             }
             union { uint32_t w[4]; bf16x8_t v; } pu, su;
 #pragma unroll
@@ -446,13 +453,13 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
                 const bf16x4_t q1 = lds_tr16(sQ + d_off(r1, chunk) + ((tp & 1) << 3));
                 const bf16x8_t gT = (bf16x8_t){g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
                 const bf16x8_t qT = (bf16x8_t){q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT, pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sf, dk[dt], 0, 0, 0);
+                dv[dt] = mfma16<DT>(gT, pf, dv[dt]);
+                dk[dt] = mfma16<DT>(qT, sf, dk[dt]);
             }
         }
         bf16_t* krow = dqkv + ((size_t)s * L + (keyok ? key : 0)) * D3 + Dm + h * 64;
-        store_rows16(dk, krow, keyok, g);
-        store_rows16(dv, krow + Dm, keyok, g);
+        store_rows16<DT>(dk, krow, keyok, g);
+        store_rows16<DT>(dv, krow + Dm, keyok, g);
     }
 #ifdef SIG_ATTN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -464,19 +471,26 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
 #endif
 }
 
-int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
-                        int S, int L, int H, hipStream_t st) {
-    SIG_CHECK_ARG(qkv && out && dout && lse && dqkv, "attn_bwd: null pointer");
-    SIG_CHECK_ARG(S > 0 && H > 0 && L > 0 && L <= ATT_KROWS, "attn_bwd: L=%d must be in 1..%d", L, ATT_KROWS);
+template <int DT>
+static void launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int S, int L,
+                            int H, hipStream_t st) {
     const int lds = 4 * ATB_ROWS * 128 + 2 * 160 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)&attn_bwd_kernel<true, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)&attn_bwd_kernel<false, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
-    else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
+    if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL((attn_bwd_kernel<true, DT>), dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
+    else hipLaunchKernelGGL((attn_bwd_kernel<false, DT>), dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
+}
+int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
+                        int S, int L, int H, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "attn_bwd");
+    SIG_CHECK_ARG(qkv && out && dout && lse && dqkv, "attn_bwd: null pointer");
+    SIG_CHECK_ARG(S > 0 && H > 0 && L > 0 && L <= ATT_KROWS, "attn_bwd: L=%d must be in 1..%d", L, ATT_KROWS);
+    if (dt == SIG_DT_F16) launch_attn_bwd<SIG_DT_F16>(qkv, out, dout, lse, dqkv, S, L, H, st);
+    else launch_attn_bwd<SIG_DT_BF16>(qkv, out, dout, lse, dqkv, S, L, H, st);
     SIG_CHECK_LAUNCH("attn_bwd");
     return 0;
 }

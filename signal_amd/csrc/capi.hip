@@ -29,60 +29,60 @@ int sig_prof_begin(int epilogue, int N, int K, int max_launches) { return sig_pr
 int sig_prof_end(double* total_ms, int* launches, double* flops) { return sig_prof_end_impl(total_ms, launches, flops); }
 
 int sig_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, int epilogue, void* out,
-                int ldo, const float* bias, const float* res, int ldr, void* aux, int ldaux, void* stream) {
+                int ldo, const float* bias, const float* res, int ldr, void* aux, int ldaux, int dtype, void* stream) {
     SigGemmNT p;
     p.A = A; p.Bt = Bt; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
-    p.out = out; p.ldo = ldo; p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0; p.colsum = nullptr;
+    p.out = out; p.ldo = ldo; p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0; p.colsum = nullptr; p.dt = dtype;
     return sig_launch_gemm_nt(p, epilogue, (hipStream_t)stream);
 }
 
 int sig_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, int Mr, int I, int J, float* out, int ldo,
-                int split, void* stream) {
+                int split, int dtype, void* stream) {
     SigGemmTN p;
     p.P = P; p.Q = Q; p.ldp = ldp; p.ldq = ldq; p.Mr = Mr; p.I = I; p.J = J; p.out = out; p.ldo = ldo;
-    p.split = split; p.m_chunk = 0; p.ws = nullptr;
+    p.split = split; p.m_chunk = 0; p.ws = nullptr; p.dt = dtype;
     return sig_launch_gemm_tn(p, (hipStream_t)stream);
 }
 
 int sig_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y_bf16, float* y_f32, float* mean,
-                      float* rstd, int M, int D, float eps, void* stream) {
-    return sig_launch_layernorm_fwd(x, gamma, beta, y_bf16, y_f32, mean, rstd, M, D, eps, (hipStream_t)stream);
+                      float* rstd, int M, int D, float eps, int dtype, void* stream) {
+    return sig_launch_layernorm_fwd(x, gamma, beta, y_bf16, y_f32, mean, rstd, M, D, eps, dtype, (hipStream_t)stream);
 }
 
 int sig_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                       const float* rstd, const float* dres, float* dx_f32, uint16_t* dx_bf16, float* dgamma, float* dbeta,
-                      int M, int D, void* stream) {
-    return sig_launch_layernorm_bwd(dy, dy_is_bf16, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D,
+                      int M, int D, int dtype, void* stream) {
+    return sig_launch_layernorm_bwd(dy, dy_is_bf16, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dtype,
                                     (hipStream_t)stream);
 }
 
-int sig_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int S, int L, int H, void* stream) {
-    return sig_launch_attn_fwd(qkv, out, lse, S, L, H, (hipStream_t)stream);
+int sig_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int S, int L, int H, int dtype, void* stream) {
+    return sig_launch_attn_fwd(qkv, out, lse, S, L, H, dtype, (hipStream_t)stream);
 }
 
 int sig_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, uint16_t* dqkv, int S,
-                 int L, int H, void* stream) {
-    return sig_launch_attn_bwd(qkv, out, dout, lse, dqkv, S, L, H, (hipStream_t)stream);
+                 int L, int H, int dtype, void* stream) {
+    return sig_launch_attn_bwd(qkv, out, dout, lse, dqkv, S, L, H, dtype, (hipStream_t)stream);
 }
 
-int sig_cast_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
-    return sig_launch_cast_bf16(src, dst, n, (hipStream_t)stream);
+int sig_cast_bf16(const float* src, uint16_t* dst, size_t n, int dtype, void* stream) {
+    return sig_launch_cast_bf16(src, dst, n, dtype, (hipStream_t)stream);
 }
-int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, void* stream) {
-    return sig_launch_transpose_cast_bf16(src, dst, rows, cols, (hipStream_t)stream);
+int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int dtype, void* stream) {
+    return sig_launch_transpose_cast_bf16(src, dst, rows, cols, dtype, (hipStream_t)stream);
 }
-int sig_transpose_cast_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, void* stream) {
-    return sig_launch_transpose_cast_multi((const long long*)table, tile_start, n, total_tiles, (hipStream_t)stream);
+int sig_transpose_cast_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, int dtype, void* stream) {
+    return sig_launch_transpose_cast_multi((const long long*)table, tile_start, n, total_tiles, dtype, (hipStream_t)stream);
 }
-int sig_colsum_bf16(const uint16_t* a, int lda, int M, int N, float* out, void* stream) {
-    return sig_launch_colsum_bf16(a, lda, M, N, out, (hipStream_t)stream);
+int sig_colsum_bf16(const uint16_t* a, int lda, int M, int N, float* out, int dtype, void* stream) {
+    return sig_launch_colsum_bf16(a, lda, M, N, out, dtype, (hipStream_t)stream);
 }
 int sig_colsum_f32(const float* a, int lda, int M, int N, float* out, void* stream) {
     return sig_launch_colsum_f32(a, lda, M, N, out, (hipStream_t)stream);
 }
 
-int sig_im2col(const float* img, uint16_t* out, int nimg, int H, int W, int P, void* stream) {
-    return sig_launch_im2col(img, out, nimg, H, W, P, (hipStream_t)stream);
+int sig_im2col(const float* img, uint16_t* out, int nimg, int H, int W, int P, int dtype, void* stream) {
+    return sig_launch_im2col(img, out, nimg, H, W, P, dtype, (hipStream_t)stream);
 }
 int sig_embed_assemble(const float* tok, const float* class_embedding, const float* positional_embedding,
                        const float* cv_embed, const int64_t* cam_label, float sie_coe, const float* ln_w,
@@ -93,16 +93,22 @@ int sig_embed_assemble(const float* tok, const float* class_embedding, const flo
 }
 int sig_embed_assemble_bwd(const float* d_pre_ln, float* dtok_f32, uint16_t* dtok_bf16, float* d_class_embedding,
                   float* d_positional_embedding, float* d_cv_embed, const int64_t* cam_label, float sie_coe, int S, int B,
-                  int L, int D, void* stream) {
+                  int L, int D, int dtype, void* stream) {
     return sig_launch_embed_bwd(d_pre_ln, dtok_f32, dtok_bf16, d_class_embedding, d_positional_embedding, d_cv_embed,
-                                cam_label, sie_coe, S, B, L, D, (hipStream_t)stream);
+                                cam_label, sie_coe, S, B, L, D, dtype, (hipStream_t)stream);
 }
 
-int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, const int* seg_end, const float* seg_lr,
-                  const float* seg_wd, int nseg, float beta1, float beta2, float eps, int step, float grad_scale, size_t n,
-                  void* stream) {
-    return sig_launch_adam(p, g, m, v, p_bf16, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, step, grad_scale, n,
+int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p16, int dtype, const int* seg_end, const float* seg_lr,
+                  const float* seg_wd, int nseg, float beta1, float beta2, float eps, int step, float grad_scale,
+                  const float* scale_state, size_t n, void* stream) {
+    return sig_launch_adam(p, g, m, v, p16, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, step, grad_scale, scale_state, dtype, n,
                            (hipStream_t)stream);
+}
+int sig_grad_check(const float* g, size_t n, float* scale_state, void* stream) {
+    return sig_launch_grad_check(g, n, scale_state, (hipStream_t)stream);
+}
+int sig_loss_scale_update(float* scale_state, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+    return sig_launch_loss_scale_update(scale_state, growth_factor, backoff_factor, growth_interval, (hipStream_t)stream);
 }
 
 int sig_bnneck_fwd(const float* x, const float* bn_w, const float* bn_b, float* running_mean, float* running_var, float momentum,

@@ -57,7 +57,7 @@ __device__ __forceinline__ void lane_swap16(uint32_t& a, uint32_t& b) {
     b = r[1];
 }
 
-template <int EPI, int TM, int TN>
+template <int EPI, int TM, int TN, int DT>
 __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)[TM][TN], int m_base, int n_base, int lane) {
     static_assert(TN % 2 == 0, "column groups are exchanged in pairs");
     constexpr bool HAS_BIAS = EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 ||
@@ -111,8 +111,8 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
             f32x4_t x = acc[i][j] + bias4[j];
             if (HAS_RES && live) x += *(const f32x4_t*)(p.res + (size_t)m * p.ldr + nc + j * 16);
             if (GELU_FWD) {
-                pu[j][0] = pack2bf(x[0], x[1]);
-                pu[j][1] = pack2bf(x[2], x[3]);
+                pu[j][0] = pack2_t<DT>(x[0], x[1]);
+                pu[j][1] = pack2_t<DT>(x[2], x[3]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = QUICK ? quick_gelu_f(x[e]) : gelu_erf_f(x[e]);
             }
@@ -120,15 +120,15 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t w = pu[j][e >> 1];
-                    const float u = bf2f((bf16_t)((e & 1) ? (w >> 16) : (w & 0xffff)));
+                    const float u = cvt16f_t<DT>((bf16_t)((e & 1) ? (w >> 16) : (w & 0xffff)));
                     x[e] *= QUICK ? quick_gelu_grad_f(u) : gelu_erf_grad_f(u);
                 }
             }
             if (OUT_F32) {
                 if (live) *(f32x4_t*)((float*)p.out + (size_t)m * p.ldo + nc + j * 16) = x;
             } else {
-                pk[j][0] = pack2bf(x[0], x[1]);
-                pk[j][1] = pack2bf(x[2], x[3]);
+                pk[j][0] = pack2_t<DT>(x[0], x[1]);
+                pk[j][1] = pack2_t<DT>(x[2], x[3]);
             }
             if (do_sum && live) csum[j] += x;   // (uniform flag: forward GEMMs request no column sums)
         }
@@ -180,7 +180,7 @@ extern "C" int sig_debug_read_stamps(unsigned long long* out, int nblocks) {
 // are 1164 tiles of 128x128 = 3 rounds of the chip's 512 slots, but 930 tiles of 160x128 = 2 rounds of 1.25x the work
 // (the same step at B = 128 per GPU, twice the tiles, runs 9 % more triplets per second).  Wave tile (BM/2) x 64 =
 // 5 x 4 MFMA tiles with 9 fragment reads per 20 MFMAs (8 per 16 at BM = 128); LDS 2 x 36 KB, still two blocks per CU.
-template <int EPI, int BM>
+template <int EPI, int BM, int DT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     static_assert(BM == 128 || BM == 160, "row tile");
     constexpr int TM = BM / 32;              // 16-row MFMA tiles per wave (wave tile = BM/2 rows x 64 columns)
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     // of an f32 row, so register stores make 64-B runs and measured slower (c_proj 11.1k -> 18.1k cycles).
     constexpr bool OUT_F32 = EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32;
     if constexpr (!OUT_F32) {
-        epilogue_regs<EPI, TM, 4>(p, acc, m0 + wm, n0 + wn, lane);
+        epilogue_regs<EPI, TM, 4, DT>(p, acc, m0 + wm, n0 + wn, lane);
     } else {
         // The wave transposes its (BM/2) x 64 f32 sub-tile through the now idle LDS, 16 rows per pass (68-float padded
         // rows: conflict-free b128 writes and reads, wave-private area) so a lane owns 8 CONSECUTIVE columns of one row:
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
 // (all DMA is issued in P3/P0: a piece needs ~900+ cycles to land, a phase lasts ~600)
 // One barrier per K-step; LDS image and swizzle as in the 128x128 kernel; same epilogues (LDS-transposed stores).
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, int DT>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
     constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[half * 4 + i][j], 0, 0, 0);
+                acc[half * 4 + i][j] = mfma16<DT>(b[j], a[i], acc[half * 4 + i][j]);
     };
 
     const int nk = p.K >> 6;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
     SIG_STAMP(ts2);
 #endif
     // ---- epilogue: straight from the accumulator registers, no LDS and no barrier ----
-    epilogue_regs<EPI, 8, 4>(p, acc, m0 + wm, n0 + wn, lane);
+    epilogue_regs<EPI, 8, 4, DT>(p, acc, m0 + wm, n0 + wn, lane);
 #ifdef SIG_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SIG_STAMP(ts3);
@@ -575,7 +575,7 @@ static int choose_band(int tn, int K, int BN) {
     return 1;
 }
 
-template <int EPI>
+template <int EPI, int DT>
 static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     SigGemmNT p = p_in;
     static int force = -1;
@@ -592,16 +592,16 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     if (big) {
         static bool attr256 = false;
         if (!attr256) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute((const void*)&gemm_nt256_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             attr256 = true;
         }
         p.band = choose_band(p.N >> 8, p.K, 256);
-        hipLaunchKernelGGL(gemm_nt256_kernel<EPI>, dim3((mp >> 8) * (p.N >> 8)), dim3(512), 131072, st, p);
+        hipLaunchKernelGGL((gemm_nt256_kernel<EPI, DT>), dim3((mp >> 8) * (p.N >> 8)), dim3(512), 131072, st, p);
     } else {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+            (void)hipFuncSetAttribute((const void*)&gemm_nt_kernel<EPI, 128, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute((const void*)&gemm_nt_kernel<EPI, 160, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
             attr_done = true;
         }
         p.band = choose_band(p.N >> 7, p.K, 128);
@@ -614,8 +614,8 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
         if (force_bm < 0) { const char* e = getenv("SIG_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
         if (force_bm == 128) tall = false;
         if (force_bm == 160) tall = tm160 * 160 <= mp;
-        if (tall) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 160>), dim3(t160), dim3(256), 73728, st, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 128>), dim3(t128), dim3(256), 65536, st, p);
+        if (tall) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 160, DT>), dim3(t160), dim3(256), 73728, st, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 128, DT>), dim3(t128), dim3(256), 65536, st, p);
     }
     if (timed) {
         (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
@@ -626,34 +626,40 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     return 0;
 }
 
-int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st) {
+template <int DT>
+static int dispatch_nt(const SigGemmNT& p, int epi, hipStream_t st) {
     SIG_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     SIG_CHECK_ARG((p.N & 127) == 0 && (p.K & 63) == 0, "gemm_nt: N=%d must be a multiple of 128 and K=%d of 64", p.N, p.K);
     SIG_CHECK_ARG((p.lda & 7) == 0 && (p.ldb & 7) == 0 && (p.ldo & 7) == 0, "gemm_nt: leading dims must keep 16-B alignment");
     SIG_CHECK_ARG(p.lda >= p.K && p.ldb >= p.K && p.ldo >= p.N, "gemm_nt: leading dimension smaller than the row");
     SIG_CHECK_ARG(p.A && p.Bt && p.out, "gemm_nt: null operand");
     switch (epi) {
-        case SIG_EPI_F32: return launch_nt<SIG_EPI_F32>(p, st);
-        case SIG_EPI_BF16: return launch_nt<SIG_EPI_BF16>(p, st);
-        case SIG_EPI_BIAS_F32: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_F32>(p, st);
-        case SIG_EPI_BIAS_BF16: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_BF16>(p, st);
+        case SIG_EPI_F32: return launch_nt<SIG_EPI_F32, DT>(p, st);
+        case SIG_EPI_BF16: return launch_nt<SIG_EPI_BF16, DT>(p, st);
+        case SIG_EPI_BIAS_F32: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_F32, DT>(p, st);
+        case SIG_EPI_BIAS_BF16: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_BF16, DT>(p, st);
         case SIG_EPI_BIAS_RES_F32:
             SIG_CHECK_ARG(p.bias && p.res && (p.ldr & 3) == 0, "gemm_nt: bias/residual missing");
-            return launch_nt<SIG_EPI_BIAS_RES_F32>(p, st);
-        case SIG_EPI_BIAS_GELU_BF16: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_GELU_BF16>(p, st);
+            return launch_nt<SIG_EPI_BIAS_RES_F32, DT>(p, st);
+        case SIG_EPI_BIAS_GELU_BF16: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_GELU_BF16, DT>(p, st);
         case SIG_EPI_DGELU_BF16:
             SIG_CHECK_ARG(p.aux && (p.ldaux & 3) == 0, "gemm_nt: pre-activation missing");
-            return launch_nt<SIG_EPI_DGELU_BF16>(p, st);
-        case SIG_EPI_BIAS_GELUERF_BF16: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_GELUERF_BF16>(p, st);
+            return launch_nt<SIG_EPI_DGELU_BF16, DT>(p, st);
+        case SIG_EPI_BIAS_GELUERF_BF16: SIG_CHECK_ARG(p.bias, "gemm_nt: bias missing"); return launch_nt<SIG_EPI_BIAS_GELUERF_BF16, DT>(p, st);
         case SIG_EPI_DGELUERF_BF16:
             SIG_CHECK_ARG(p.aux && (p.ldaux & 3) == 0, "gemm_nt: pre-activation missing");
-            return launch_nt<SIG_EPI_DGELUERF_BF16>(p, st);
+            return launch_nt<SIG_EPI_DGELUERF_BF16, DT>(p, st);
         case SIG_EPI_RES_F32:
             SIG_CHECK_ARG(p.res && (p.ldr & 3) == 0, "gemm_nt: residual missing");
-            return launch_nt<SIG_EPI_RES_F32>(p, st);
+            return launch_nt<SIG_EPI_RES_F32, DT>(p, st);
     }
     sig_set_error("gemm_nt: unknown epilogue %d", epi);
     return 1;
+}
+
+int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st) {
+    SIG_CHECK_DT(p.dt, "gemm_nt");
+    return p.dt == SIG_DT_F16 ? dispatch_nt<SIG_DT_F16>(p, epi, st) : dispatch_nt<SIG_DT_BF16>(p, epi, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,6 +672,7 @@ int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st) {
 // the 8 distinct 32-B ranges of the 256-B bank row.
 // MFMA 32x32x16 so that one accumulator register is two 128-B row segments: the shape at which global
 // f32 atomics run at full rate (MI355X_MICROARCH 'Global float atomics').
+template <int DT>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(SigGemmTN p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(SigGemmTN p) {
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[kk][a], qf[kk][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = mfma32<DT>(pf[kk][a], qf[kk][b], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -779,6 +786,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(SigGemmTN p) {
 // Fewer, larger blocks also fill the chip better: c_fc wgrad = 36 tiles x 7 row chunks = 252 blocks on 256 CUs,
 // against 144 x 3 = 432 blocks of the 128x128 kernel on 512 slots.
 // ------------------------------------------------------------------------------------------------
+template <int DT>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(SigGemmTN p) {
     constexpr int ROWB = 512, OPB = 64 * ROWB, STAGE = 2 * OPB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(SigGemmTN p) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < 2; ++b) acc[a][b] = mfma32<DT>(pf[a], qf[b], acc[a][b]);
     };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
@@ -984,7 +992,8 @@ static float* tn_workspace(hipStream_t st, size_t bytes) {
     return ptr;
 }
 
-int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
+template <int DT>
+static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {
     SigGemmTN p = p_in;
     SIG_CHECK_ARG(p.Mr > 0 && (p.Mr & 63) == 0, "gemm_tn: row count %d must be a positive multiple of 64 (pad rows zeroed)", p.Mr);
     SIG_CHECK_ARG((p.I & 127) == 0 && (p.J & 127) == 0 && p.I > 0 && p.J > 0, "gemm_tn: I=%d, J=%d must be multiples of 128", p.I, p.J);
@@ -992,7 +1001,7 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
     SIG_CHECK_ARG(p.P && p.Q && p.out, "gemm_tn: null operand");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)&gemm_tn_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_done = true;
     }
     const int ksteps = p.Mr >> 6;
@@ -1007,7 +1016,7 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
     if (big) {
         static bool attr256 = false;
         if (!attr256) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute((const void*)&gemm_tn256_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             attr256 = true;
         }
         const int tiles = (p.I >> 8) * (p.J >> 8);
@@ -1020,7 +1029,16 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
         static int use_ws = -1;
         if (use_ws < 0) { const char* e = getenv("SIG_GEMM_TN_ATOMICS"); use_ws = e && atoi(e) ? 0 : 1; }
         p.ws = use_ws ? tn_workspace(st, (size_t)tiles * split * 65536 * sizeof(float)) : nullptr;
-        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * split), dim3(512), 131072, st, p);
+        // bench.py's roofline leg: class SIG_PROF_TN256 times every launch of this kernel (N/K = 0) or one (I, J) shape
+        const bool timed = g_prof.on && g_prof.epi == SIG_PROF_TN256 && (g_prof.N == 0 || (g_prof.N == p.I && g_prof.K == p.J)) &&
+                           g_prof.used + 2 <= g_prof.ev.size();
+        if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+        hipLaunchKernelGGL(gemm_tn256_kernel<DT>, dim3(tiles * split), dim3(512), 131072, st, p);
+        if (timed) {
+            (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+            g_prof.used += 2;
+            g_prof.flops += 2.0 * p.Mr * p.I * p.J;
+        }
         SIG_CHECK_LAUNCH("gemm_tn256");
         if (p.ws) {
             hipLaunchKernelGGL(tn_reduce_kernel, dim3(sig_ceil_div(p.I * (p.J >> 2), 256)), dim3(256), 0, st, p.ws, p.out, p.I, p.J, p.ldo,
@@ -1040,7 +1058,12 @@ int sig_launch_gemm_tn(const SigGemmTN& p_in, hipStream_t st) {
     const int per = sig_ceil_div(ksteps, split);
     split = sig_ceil_div(ksteps, per);
     p.m_chunk = per * 64;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * split), dim3(256), 65536, st, p);
+    hipLaunchKernelGGL(gemm_tn_kernel<DT>, dim3(tiles * split), dim3(256), 65536, st, p);
     SIG_CHECK_LAUNCH("gemm_tn");
     return 0;
+}
+
+int sig_launch_gemm_tn(const SigGemmTN& p, hipStream_t st) {
+    SIG_CHECK_DT(p.dt, "gemm_tn");
+    return p.dt == SIG_DT_F16 ? launch_tn<SIG_DT_F16>(p, st) : launch_tn<SIG_DT_BF16>(p, st);
 }

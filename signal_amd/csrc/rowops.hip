@@ -14,7 +14,7 @@
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ yb,
                                                             float* __restrict__ yf, float* __restrict__ mean,
-                                                            float* __restrict__ rstd, int M, int D, float eps) {
+                                                            float* __restrict__ rstd, int M, int D, float eps, int dt) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -55,17 +55,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             o.z = (v[it].z - mu) * rs * g.z + b.z;
             o.w = (v[it].w - mu) * rs * g.w + b.w;
             if (yf) *(float4*)(yf + (size_t)row * D + c) = o;
-            if (yb) *(uint2*)(yb + (size_t)row * D + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+            if (yb) *(uint2*)(yb + (size_t)row * D + c) = make_uint2(pack2_16(o.x, o.y, dt), pack2_16(o.z, o.w, dt));
         }
     }
 }
 
 int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y_bf16, float* y_f32,
-                             float* mean, float* rstd, int M, int D, float eps, hipStream_t st) {
+                             float* mean, float* rstd, int M, int D, float eps, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "layernorm_fwd");
     SIG_CHECK_ARG(M > 0 && D > 0 && (D & 3) == 0 && D <= 256 * LN_MAXV, "layernorm_fwd: D=%d unsupported (multiple of 4, <= 1024)", D);
     SIG_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(sig_ceil_div(M, 4)), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32,
-                       mean, rstd, M, D, eps);
+                       mean, rstd, M, D, eps, dt);
     SIG_CHECK_LAUNCH("layernorm_fwd");
     return 0;
 }
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dxf, bf16_t* __restrict__ dxb,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D,
-                                                            float* __restrict__ dxsum) {
+                                                            float* __restrict__ dxsum, int dt) {
     // NV = float4 per lane (D <= 256*NV): sized to the row so the per-lane accumulators stay small (more waves per SIMD).
     // Column sums (dgamma, dbeta, optional sum of dx): every wave parks its accumulators in its own LDS slice (plain
     // b128 stores), the block adds the slices and issues one global atomic per column.  That flush runs at the
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
             if (c < D) {
                 if (DY_BF16) {
                     const uint2 u = *(const uint2*)((const bf16_t*)dy_ + (size_t)row * D + c);
-                    dyv[it] = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)),
-                                          bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+                    dyv[it] = make_float4(cvt16f((bf16_t)(u.x & 0xffff), dt), cvt16f((bf16_t)(u.x >> 16), dt),
+                                          cvt16f((bf16_t)(u.y & 0xffff), dt), cvt16f((bf16_t)(u.y >> 16), dt));
                 } else {
                     dyv[it] = *(const float4*)((const float*)dy_ + (size_t)row * D + c);
                 }
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
                 o.z = rs * (dyv[it].z * g.z - m1 - xh[it].z * m2) + rv[it].z;
                 o.w = rs * (dyv[it].w * g.w - m1 - xh[it].w * m2) + rv[it].w;
                 if (dxf) *(float4*)(dxf + (size_t)row * D + c) = o;
-                if (dxb) *(uint2*)(dxb + (size_t)row * D + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+                if (dxb) *(uint2*)(dxb + (size_t)row * D + c) = make_uint2(pack2_16(o.x, o.y, dt), pack2_16(o.z, o.w, dt));
                 if (SUMX) { ax[it].x += o.x; ax[it].y += o.y; ax[it].z += o.z; ax[it].w += o.w; }
             }
         }
@@ -186,19 +187,20 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
 template <bool DY_BF16, int NV>
 static void launch_ln_bwd(int blocks, hipStream_t st, const void* dy, const float* x, const float* gamma, const float* mean,
                           const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma, float* dbeta, int M,
-                          int D, float* dx_colsum) {
+                          int D, float* dx_colsum, int dt) {
     constexpr int WPB = LN_BWD_WPB;
     if (dx_colsum)
         hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, true, WPB>), dim3(blocks), dim3(64 * WPB), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum);
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt);
     else
         hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, false, WPB>), dim3(blocks), dim3(64 * WPB), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum);
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt);
 }
 
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                              const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma,
-                             float* dbeta, int M, int D, hipStream_t st, float* dx_colsum) {
+                             float* dbeta, int M, int D, int dt, hipStream_t st, float* dx_colsum) {
+    SIG_CHECK_DT(dt, "layernorm_bwd");
     SIG_CHECK_ARG(M > 0 && D > 0 && (D & 3) == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D=%d unsupported", D);
     SIG_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "layernorm_bwd: null pointer");
     SIG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
@@ -209,7 +211,7 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     const int k = sig_ceil_div(M, LN_BWD_WPB * cap);
     int blocks = sig_ceil_div(M, LN_BWD_WPB * (k > 0 ? k : 1));
     const int nv = (D + 255) / 256;
-#define SIG_LN(BF, NV_) launch_ln_bwd<BF, NV_>(blocks, st, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum)
+#define SIG_LN(BF, NV_) launch_ln_bwd<BF, NV_>(blocks, st, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt)
     if (dy_is_bf16) {
         if (nv == 1) SIG_LN(true, 1); else if (nv == 2) SIG_LN(true, 2); else if (nv == 3) SIG_LN(true, 3); else SIG_LN(true, 4);
     } else {
@@ -223,29 +225,30 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n, int dt) {
     const size_t stride = (size_t)gridDim.x * 256 * 8;
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
         if (i + 8 <= n) {
             const float4 a = *(const float4*)(src + i), b = *(const float4*)(src + i + 4);
-            *(uint4*)(dst + i) = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+            *(uint4*)(dst + i) = make_uint4(pack2_16(a.x, a.y, dt), pack2_16(a.z, a.w, dt), pack2_16(b.x, b.y, dt), pack2_16(b.z, b.w, dt));
         } else {
-            for (size_t k = i; k < n; ++k) dst[k] = f2bf(src[k]);
+            for (size_t k = i; k < n; ++k) dst[k] = f2cvt16(src[k], dt);
         }
     }
 }
-int sig_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st) {
+int sig_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "cast");
     SIG_CHECK_ARG(src && dst && n > 0, "cast_bf16: bad arguments");
     SIG_CHECK_ARG((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, "cast_bf16: pointers must be 16-B aligned");
     size_t blocks = (n + 2047) / 2048;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n, dt);
     SIG_CHECK_LAUNCH("cast_bf16");
     return 0;
 }
 
 // dst[c][r] = bf16(src[r][c]);  64x64 tile through LDS (65-float rows: conflict-free column reads)
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols) {
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols, int dt) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -253,18 +256,19 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
         tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(size_t)(r0 + r) * cols + c0 + tx] : 0.f;
     __syncthreads();
     for (int c = ty; c < 64; c += 4)
-        if (c0 + c < cols && r0 + tx < rows) dst[(size_t)(c0 + c) * rows + r0 + tx] = f2bf(tile[tx][c]);
+        if (c0 + c < cols && r0 + tx < rows) dst[(size_t)(c0 + c) * rows + r0 + tx] = f2cvt16(tile[tx][c], dt);
 }
-int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st) {
+int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int cols, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "transpose_cast");
     SIG_CHECK_ARG(src && dst && rows > 0 && cols > 0, "transpose_cast: bad arguments");
-    hipLaunchKernelGGL(transpose_cast_kernel, dim3(sig_ceil_div(cols, 64), sig_ceil_div(rows, 64)), dim3(256), 0, st, src, dst, rows, cols);
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3(sig_ceil_div(cols, 64), sig_ceil_div(rows, 64)), dim3(256), 0, st, src, dst, rows, cols, dt);
     SIG_CHECK_LAUNCH("transpose_cast");
     return 0;
 }
 
 // All transposed weight copies of a step in ONE launch: table[d] = {src f32*, dst bf16*, rows, cols} (as int64),
 // tile_start[d] = first 64x64 tile of matrix d in the flattened grid (tile_start[n] = total).
-__global__ __launch_bounds__(256) void transpose_cast_multi_kernel(const long long* __restrict__ table, const int* __restrict__ tile_start, int n) {
+__global__ __launch_bounds__(256) void transpose_cast_multi_kernel(const long long* __restrict__ table, const int* __restrict__ tile_start, int n, int dt) {
     __shared__ float tile[64][65];
     int lo = 0, hi = n - 1;
     const int b = blockIdx.x;
@@ -282,11 +286,12 @@ __global__ __launch_bounds__(256) void transpose_cast_multi_kernel(const long lo
         tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(size_t)(r0 + r) * cols + c0 + tx] : 0.f;
     __syncthreads();
     for (int c = ty; c < 64; c += 4)
-        if (c0 + c < cols && r0 + tx < rows) dst[(size_t)(c0 + c) * rows + r0 + tx] = f2bf(tile[tx][c]);
+        if (c0 + c < cols && r0 + tx < rows) dst[(size_t)(c0 + c) * rows + r0 + tx] = f2cvt16(tile[tx][c], dt);
 }
-int sig_launch_transpose_cast_multi(const long long* table, const int* tile_start, int n, int total_tiles, hipStream_t st) {
+int sig_launch_transpose_cast_multi(const long long* table, const int* tile_start, int n, int total_tiles, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "transpose_cast_multi");
     SIG_CHECK_ARG(table && tile_start && n > 0 && total_tiles > 0, "transpose_cast_multi: bad arguments");
-    hipLaunchKernelGGL(transpose_cast_multi_kernel, dim3(total_tiles), dim3(256), 0, st, table, tile_start, n);
+    hipLaunchKernelGGL(transpose_cast_multi_kernel, dim3(total_tiles), dim3(256), 0, st, table, tile_start, n, dt);
     SIG_CHECK_LAUNCH("transpose_cast_multi");
     return 0;
 }
@@ -295,7 +300,7 @@ int sig_launch_transpose_cast_multi(const long long* table, const int* tile_star
 // column sums (bias gradients): out[n] += sum_m a[m][n]
 // ------------------------------------------------------------------------------------------------
 template <bool BF16>
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ a_, int lda, int M, int N, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ a_, int lda, int M, int N, float* __restrict__ out, int dt) {
     constexpr int CPL = BF16 ? 8 : 4;  // columns per lane (16 B)
     __shared__ float red[4][64 * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -306,10 +311,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ a_
         for (int r = rbeg; r < rbeg + 32 && r < M; ++r) {
             if (BF16) {
                 const uint4 u = *(const uint4*)((const bf16_t*)a_ + (size_t)r * lda + c);
-                acc[0] += bf2f((bf16_t)(u.x & 0xffff)); acc[1] += bf2f((bf16_t)(u.x >> 16));
-                acc[2] += bf2f((bf16_t)(u.y & 0xffff)); acc[3] += bf2f((bf16_t)(u.y >> 16));
-                acc[4] += bf2f((bf16_t)(u.z & 0xffff)); acc[5] += bf2f((bf16_t)(u.z >> 16));
-                acc[6] += bf2f((bf16_t)(u.w & 0xffff)); acc[7] += bf2f((bf16_t)(u.w >> 16));
+                acc[0] += cvt16f((bf16_t)(u.x & 0xffff), dt); acc[1] += cvt16f((bf16_t)(u.x >> 16), dt);
+                acc[2] += cvt16f((bf16_t)(u.y & 0xffff), dt); acc[3] += cvt16f((bf16_t)(u.y >> 16), dt);
+                acc[4] += cvt16f((bf16_t)(u.z & 0xffff), dt); acc[5] += cvt16f((bf16_t)(u.z >> 16), dt);
+                acc[6] += cvt16f((bf16_t)(u.w & 0xffff), dt); acc[7] += cvt16f((bf16_t)(u.w >> 16), dt);
             } else {
                 const float4 v = *(const float4*)((const float*)a_ + (size_t)r * lda + c);
                 acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
@@ -324,15 +329,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ a_
         if (col < N) atomicAdd(out + col, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
     }
 }
-int sig_launch_colsum_bf16(const bf16_t* a, int lda, int M, int N, float* out, hipStream_t st) {
+int sig_launch_colsum_bf16(const bf16_t* a, int lda, int M, int N, float* out, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "colsum");
     SIG_CHECK_ARG(a && out && M > 0 && N > 0 && (N & 7) == 0 && (lda & 7) == 0, "colsum_bf16: N and lda must be multiples of 8");
-    hipLaunchKernelGGL(colsum_kernel<true>, dim3(sig_ceil_div(M, 128), sig_ceil_div(N, 512)), dim3(256), 0, st, a, lda, M, N, out);
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3(sig_ceil_div(M, 128), sig_ceil_div(N, 512)), dim3(256), 0, st, a, lda, M, N, out, dt);
     SIG_CHECK_LAUNCH("colsum_bf16");
     return 0;
 }
 int sig_launch_colsum_f32(const float* a, int lda, int M, int N, float* out, hipStream_t st) {
     SIG_CHECK_ARG(a && out && M > 0 && N > 0 && (N & 3) == 0 && (lda & 3) == 0, "colsum_f32: N and lda must be multiples of 4");
-    hipLaunchKernelGGL(colsum_kernel<false>, dim3(sig_ceil_div(M, 128), sig_ceil_div(N, 256)), dim3(256), 0, st, a, lda, M, N, out);
+    hipLaunchKernelGGL(colsum_kernel<false>, dim3(sig_ceil_div(M, 128), sig_ceil_div(N, 256)), dim3(256), 0, st, a, lda, M, N, out, 0);
     SIG_CHECK_LAUNCH("colsum_f32");
     return 0;
 }
@@ -341,7 +347,7 @@ int sig_launch_colsum_f32(const float* a, int lda, int M, int N, float* out, hip
 // patch gather: img f32 [nimg,3,H,W] -> bf16 [nimg*h*w, 3*P*P], column = c*P*P + dy*P + dx
 // (the im2col of the stride-16 conv at clip/model.py:433,448-450).  Thread = 8 consecutive pixels.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int nimg, int H, int W, int P) {
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int nimg, int H, int W, int P, int dt) {
     const int w8 = W >> 3;
     const size_t total = (size_t)nimg * 3 * H * w8;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
@@ -357,16 +363,17 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
         const int wg = W / P, hg = H / P;
         const size_t row = ((size_t)n * hg + pi) * wg + pj;
         bf16_t* dst = out + row * (size_t)(3 * P * P) + c * P * P + dy * P + dx;
-        *(uint4*)dst = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+        *(uint4*)dst = make_uint4(pack2_16(a.x, a.y, dt), pack2_16(a.z, a.w, dt), pack2_16(b.x, b.y, dt), pack2_16(b.z, b.w, dt));
     }
 }
-int sig_launch_im2col(const float* img, bf16_t* out, int nimg, int H, int W, int P, hipStream_t st) {
+int sig_launch_im2col(const float* img, bf16_t* out, int nimg, int H, int W, int P, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "im2col");
     SIG_CHECK_ARG(img && out && nimg > 0, "im2col: bad arguments");
     SIG_CHECK_ARG(P % 8 == 0 && H % P == 0 && W % P == 0, "im2col: patch %d must be a multiple of 8 and divide %dx%d", P, H, W);
     const size_t total = (size_t)nimg * 3 * H * (W >> 3);
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, out, nimg, H, W, P);
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, out, nimg, H, W, P, dt);
     SIG_CHECK_LAUNCH("im2col");
     return 0;
 }
@@ -459,7 +466,7 @@ int sig_launch_embed_assemble(const float* tok, const float* cls_emb, const floa
 #define EMB_BWD_CHUNKS 8
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dpre, float* __restrict__ dtokf, bf16_t* __restrict__ dtokb,
                                                         float* __restrict__ dcls, float* __restrict__ dpos, float* __restrict__ dcv,
-                                                        const int64_t* __restrict__ cam, float sie, int S, int B, int L, int D) {
+                                                        const int64_t* __restrict__ cam, float sie, int S, int B, int L, int D, int dt) {
     const int l = blockIdx.x;
     const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
     if (c >= D) return;
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         } else {
             const size_t o = ((size_t)s * (L - 1) + (l - 1)) * D + c;
             if (dtokf) *(f32x4_t*)(dtokf + o) = v;
-            if (dtokb) *(uint2*)(dtokb + o) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            if (dtokb) *(uint2*)(dtokb + o) = make_uint2(pack2_16(v[0], v[1], dt), pack2_16(v[2], v[3], dt));
         }
     }
     if (s1 <= s0) return;
@@ -489,12 +496,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     }
 }
 int sig_launch_embed_bwd(const float* dx_pre, float* dtok_f32, bf16_t* dtok_bf16, float* dcls, float* dpos,
-                         float* dcv, const int64_t* cam, float sie_coe, int S, int B, int L, int D, hipStream_t st) {
+                         float* dcv, const int64_t* cam, float sie_coe, int S, int B, int L, int D, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "embed_bwd");
     SIG_CHECK_ARG(dx_pre && dcls && dpos && (dtok_f32 || dtok_bf16), "embed_bwd: null pointer");
     SIG_CHECK_ARG((dcv == nullptr) || cam, "embed_bwd: cam labels missing");
     SIG_CHECK_ARG((D & 3) == 0, "embed_bwd: D=%d must be a multiple of 4", D);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(L, EMB_BWD_CHUNKS, sig_ceil_div(D, 1024)), dim3(256), 0, st, dx_pre, dtok_f32, dtok_bf16,
-                       dcls, dpos, dcv, cam, sie_coe, S, B, L, D);
+                       dcls, dpos, dcv, cam, sie_coe, S, B, L, D, dt);
     SIG_CHECK_LAUNCH("embed_bwd");
     return 0;
 }

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "../../include/signal_hip.h"
+
 typedef uint16_t bf16_t;  // raw bf16 bits; all bf16 tensors cross the C ABI as uint16_t*
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
@@ -47,6 +49,41 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     const f32x2_native_t f = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_native_t));
 }
+
+// ---- f16 <-> f32, and the operand-type switch ---------------------------------------------------
+// Every 16-bit tensor of the path holds ONE operand type per model: bf16 (DT = SIG_DT_BF16) or IEEE f16 (SIG_DT_F16).
+// Same MFMA rate on gfx950 (v_mfma_f32_16x16x32_{bf16,f16}); f16 keeps 3 more mantissa bits (operand rounding 2^-11
+// instead of 2^-8), which is what the reference's CUDA autocast computes in (engine/processor.py:165).  The
+// matrix-core kernels take the type as a template parameter; the HBM-bound row kernels take it as a (uniform) argument.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;   // (SIG_DT_BF16 / SIG_DT_F16 come from include/signal_hip.h)
+__device__ __forceinline__ float h2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f2h(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {     // ONE v_cvt_pk_f16_f32 (round to nearest even)
+    typedef _Float16 f16x2_native_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_native_t __attribute__((ext_vector_type(2)));
+    const f32x2_native_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2_native_t));
+}
+__device__ __forceinline__ float cvt16f(bf16_t v, int dt) { return dt == SIG_DT_F16 ? h2f(v) : bf2f(v); }
+__device__ __forceinline__ bf16_t f2cvt16(float f, int dt) { return dt == SIG_DT_F16 ? f2h(f) : f2bf(f); }
+__device__ __forceinline__ uint32_t pack2_16(float lo, float hi, int dt) { return dt == SIG_DT_F16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+template <int DT> __device__ __forceinline__ float cvt16f_t(bf16_t v) { return DT == SIG_DT_F16 ? h2f(v) : bf2f(v); }
+template <int DT> __device__ __forceinline__ uint32_t pack2_t(float lo, float hi) { return DT == SIG_DT_F16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+template <int DT> __device__ __forceinline__ bf16_t f2cvt16_t(float f) { return DT == SIG_DT_F16 ? f2h(f) : f2bf(f); }
+// MFMA on raw 16-bit fragments (the bit patterns are typed by DT)
+template <int DT> __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    if constexpr (DT == SIG_DT_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <int DT> __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    if constexpr (DT == SIG_DT_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#define SIG_CHECK_DT(dt, who) SIG_CHECK_ARG((dt) == SIG_DT_BF16 || (dt) == SIG_DT_F16, "%s: operand dtype %d is neither bf16 (0) nor f16 (1)", who, (int)(dt))
 
 // ---- wave reductions (64 lanes) ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

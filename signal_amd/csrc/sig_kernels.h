@@ -30,8 +30,12 @@ struct SigGemmNT {
     int ldaux;
     int band;          // column tiles per L2-resident weight band (filled by the launcher)
     float* colsum;     // optional [N]: += column sums of the (f32, pre-rounding) output over the valid rows
+    int dt;            // SIG_DT_BF16 / SIG_DT_F16: type of A, Bt, aux and of 16-bit outputs
 };
 int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st);
+#ifndef SIG_PROF_TN256
+#define SIG_PROF_TN256 100   // sig_prof_begin class: gemm_tn256_kernel launches (N = I, K = J; 0 = any shape)
+#endif
 int sig_prof_begin_impl(int epi, int N, int K, int max_launches);
 int sig_prof_end_impl(double* total_ms, int* launches, double* flops);
 
@@ -45,63 +49,68 @@ struct SigGemmTN {
     int split;        // 0 = choose
     int m_chunk;      // filled by the launcher
     float* ws;        // filled by the launcher: per-block partial tiles (256x256 kernel), nullptr = atomics into out
+    int dt;           // SIG_DT_BF16 / SIG_DT_F16: type of P and Q
 };
 int sig_launch_gemm_tn(const SigGemmTN& p, hipStream_t st);
 
 // ---- row-wise kernels (rowops.hip) ----------------------------------------------------------------
 int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y_bf16, float* y_f32,
-                             float* mean, float* rstd, int M, int D, float eps, hipStream_t st);
+                             float* mean, float* rstd, int M, int D, float eps, int dt, hipStream_t st);
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                              const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma,
-                             float* dbeta, int M, int D, hipStream_t st, float* dx_colsum = nullptr);
-int sig_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
-int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st);
-int sig_launch_transpose_cast_multi(const long long* table, const int* tile_start, int n, int total_tiles, hipStream_t st);
-int sig_launch_colsum_bf16(const bf16_t* a, int lda, int M, int N, float* out, hipStream_t st);
+                             float* dbeta, int M, int D, int dt, hipStream_t st, float* dx_colsum = nullptr);
+int sig_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, int dt, hipStream_t st);
+int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int cols, int dt, hipStream_t st);
+int sig_launch_transpose_cast_multi(const long long* table, const int* tile_start, int n, int total_tiles, int dt, hipStream_t st);
+int sig_launch_colsum_bf16(const bf16_t* a, int lda, int M, int N, float* out, int dt, hipStream_t st);
 int sig_launch_colsum_f32(const float* a, int lda, int M, int N, float* out, hipStream_t st);
-int sig_launch_im2col(const float* img, bf16_t* out, int nimg, int H, int W, int P, hipStream_t st);
+int sig_launch_im2col(const float* img, bf16_t* out, int nimg, int H, int W, int P, int dt, hipStream_t st);
 int sig_launch_embed_assemble(const float* tok, const float* cls_emb, const float* pos, const float* cv_embed,
                               const int64_t* cam, float sie_coe, const float* g, const float* b, float* x,
                               float* pre_ln, float* mean, float* rstd, int S, int B, int L, int D, float eps,
                               hipStream_t st);
 int sig_launch_embed_bwd(const float* dx_pre, float* dtok_f32, bf16_t* dtok_bf16, float* dcls, float* dpos,
-                         float* dcv, const int64_t* cam, float sie_coe, int S, int B, int L, int D, hipStream_t st);
+                         float* dcv, const int64_t* cam, float sie_coe, int S, int B, int L, int D, int dt, hipStream_t st);
 
 // ---- attention (attention.hip) ---------------------------------------------------------------------
-int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, hipStream_t st);
+int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, int dt, hipStream_t st);
 // ---- SIM (sim.hip) ------------------------------------------------------------------------------------
 int sig_launch_sim_select(const float* tokens, int B, int L, const float* Wq, const float* bq, const float* Wk,
                           const float* bk, int topk, float* qprime, float* cconst, float* intra, float* inter,
                           float* mask_f, unsigned char* mask_u8, hipStream_t st);
 int sig_launch_sim_gather(const float* tokens, const float* mask_f, int B, int L, bf16_t* sel, bf16_t* cls_b, float* cls_f,
-                          hipStream_t st);
+                          int dt, hipStream_t st);
 int sig_launch_sim_gather_bwd(const bf16_t* dsel, const float* dcls, const float* mask_f, int B, int L, float* dtokens,
-                              hipStream_t st);
-int sig_launch_xattn_fwd(const float* q, const bf16_t* kv, int B, int NK, bf16_t* out, float* probs, hipStream_t st);
+                              int dt, hipStream_t st);
+int sig_launch_xattn_fwd(const float* q, const bf16_t* kv, int B, int NK, bf16_t* out, float* probs, int dt, hipStream_t st);
 int sig_launch_xattn_bwd(const float* q, const bf16_t* kv, const float* probs, const float* dout, int B, int NK, float* dq,
-                         bf16_t* dkv, hipStream_t st);
+                         bf16_t* dkv, int dt, hipStream_t st);
 
 int sig_launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
-                        int S, int L, int H, hipStream_t st);
+                        int S, int L, int H, int dt, hipStream_t st);
 
 // ---- GAM / LAM (align.hip) ------------------------------------------------------------------------------
 int sig_launch_gam_fwd(const float* tokens, int B, int L, const float* temp, float* fh, float* nrm, float* lv, float* la,
                        float* vec, float* coef, float* loss, hipStream_t st);
 int sig_launch_gam_bwd(const float* fh, const float* nrm, const float* coef, const float* dloss, int B, int L, float* dtokens,
                        float* dtemp, hipStream_t st);
-int sig_launch_lam_gather(const float* tokens, int B, int L, bf16_t* xb, size_t xstride, hipStream_t st);
+int sig_launch_lam_gather(const float* tokens, int B, int L, bf16_t* xb, size_t xstride, int dt, hipStream_t st);
 int sig_launch_lam_scatter_add(const float* src, int m, int B, int L, float* dtokens, hipStream_t st);
 int sig_launch_lam_tail_fwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const float* wd,
-                            const float* bd, const float* w4, float* a2pre, float* offs, float* samp, hipStream_t st);
+                            const float* bd, const float* w4, float* a2pre, float* offs, float* samp, int dt, hipStream_t st);
 int sig_launch_lam_loss(const float* samp, size_t n, float* loss, hipStream_t st);
 int sig_launch_lam_tail_bwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre,
                             const float* wd, const float* w4, const float* a2pre, const float* offs, const float* samp_all,
                             size_t nsamp, const float* dloss, bf16_t* da1pre, float* dwd, float* dbd, float* dw4, float* dtokens,
-                            hipStream_t st, float* partials = nullptr);
+                            int dt, hipStream_t st, float* partials = nullptr);
 
 // ---- optimizer (optim.hip) ------------------------------------------------------------------------------
 int sig_launch_adam(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, const int* seg_end, const float* seg_lr,
-                    const float* seg_wd, int nseg, float b1, float b2, float eps, int step, float gscale, size_t n, hipStream_t st);
+                    const float* seg_wd, int nseg, float b1, float b2, float eps, int step, float gscale, const float* scale_state, int dt,
+                    size_t n, hipStream_t st);
+// fp16 loss scaling (engine/processor.py:119,259-261): state = [scale, 1/scale, found_inf, growth_tracker, applied_steps]
+int sig_launch_grad_check(const float* g, size_t n, float* state, hipStream_t st);
+int sig_launch_loss_scale_update(float* state, float growth, float backoff, int interval, hipStream_t st);
 
 // ---- ReID head (reid.hip) ----------------------------------------------------------------------------------
 int sig_launch_bnneck_fwd(const float* x, const float* bn_w, const float* bn_b, float* run_mean, float* run_var, float momentum,

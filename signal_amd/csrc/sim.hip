@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void sim_select_kernel(const float* __restrict
 // also emits the stacked CLS queries cls_b[(b*3+m)][:] (bf16) and cls_f (f32) used by the interaction block
 __global__ __launch_bounds__(256) void sim_gather_kernel(const float* __restrict__ tokens, const float* __restrict__ mask_f,
                                                          int L, int B, bf16_t* __restrict__ sel, bf16_t* __restrict__ cls_b,
-                                                         float* __restrict__ cls_f) {
+                                                         float* __restrict__ cls_f, int dt) {
     const int Lp = L - 1;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -191,14 +191,14 @@ __global__ __launch_bounds__(256) void sim_gather_kernel(const float* __restrict
         if (on) {
             const float* t = tokens + ((size_t)s * L + 1 + j) * SIM_D + lane * 8;
             const float4 a = *(const float4*)t, c = *(const float4*)(t + 4);
-            o = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(c.x, c.y), pack2bf(c.z, c.w));
+            o = make_uint4(pack2_16(a.x, a.y, dt), pack2_16(a.z, a.w, dt), pack2_16(c.x, c.y, dt), pack2_16(c.z, c.w, dt));
         }
         *(uint4*)(sel + (size_t)row * SIM_D + lane * 8) = o;
     } else if (row < nsel + 3 * B) {
         const int bm = row - nsel, m = bm % 3, b = bm / 3;
         const float* t = tokens + (size_t)(m * B + b) * L * SIM_D + lane * 8;
         const float4 a = *(const float4*)t, c = *(const float4*)(t + 4);
-        *(uint4*)(cls_b + (size_t)bm * SIM_D + lane * 8) = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(c.x, c.y), pack2bf(c.z, c.w));
+        *(uint4*)(cls_b + (size_t)bm * SIM_D + lane * 8) = make_uint4(pack2_16(a.x, a.y, dt), pack2_16(a.z, a.w, dt), pack2_16(c.x, c.y, dt), pack2_16(c.z, c.w, dt));
         *(float4*)(cls_f + (size_t)bm * SIM_D + lane * 8) = a;
         *(float4*)(cls_f + (size_t)bm * SIM_D + lane * 8 + 4) = c;
     }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void sim_gather_kernel(const float* __restrict
 // backward of the gather: dtokens[s][1+j][:] += mask * dsel[(b*3+m)*Lp+j][:]; dtokens[s][0][:] += dcls[(b*3+m)][:]
 __global__ __launch_bounds__(256) void sim_gather_bwd_kernel(const bf16_t* __restrict__ dsel, const float* __restrict__ dcls,
                                                              const float* __restrict__ mask_f, int L, int B,
-                                                             float* __restrict__ dtokens) {
+                                                             float* __restrict__ dtokens, int dt) {
     const int Lp = L - 1;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -218,10 +218,10 @@ __global__ __launch_bounds__(256) void sim_gather_bwd_kernel(const bf16_t* __res
         const uint4 u = *(const uint4*)(dsel + (size_t)row * SIM_D + lane * 8);
         float* t = dtokens + ((size_t)(m * B + b) * L + 1 + j) * SIM_D + lane * 8;
         float4 a = *(float4*)t, c = *(float4*)(t + 4);
-        a.x += bf2f((bf16_t)(u.x & 0xffff)); a.y += bf2f((bf16_t)(u.x >> 16));
-        a.z += bf2f((bf16_t)(u.y & 0xffff)); a.w += bf2f((bf16_t)(u.y >> 16));
-        c.x += bf2f((bf16_t)(u.z & 0xffff)); c.y += bf2f((bf16_t)(u.z >> 16));
-        c.z += bf2f((bf16_t)(u.w & 0xffff)); c.w += bf2f((bf16_t)(u.w >> 16));
+        a.x += cvt16f((bf16_t)(u.x & 0xffff), dt); a.y += cvt16f((bf16_t)(u.x >> 16), dt);
+        a.z += cvt16f((bf16_t)(u.y & 0xffff), dt); a.w += cvt16f((bf16_t)(u.y >> 16), dt);
+        c.x += cvt16f((bf16_t)(u.z & 0xffff), dt); c.y += cvt16f((bf16_t)(u.z >> 16), dt);
+        c.z += cvt16f((bf16_t)(u.w & 0xffff), dt); c.w += cvt16f((bf16_t)(u.w >> 16), dt);
         *(float4*)t = a;
         *(float4*)(t + 4) = c;
     } else if (row < nsel + 3 * B) {
@@ -254,19 +254,21 @@ int sig_launch_sim_select(const float* tokens, int B, int L, const float* Wq, co
 }
 
 int sig_launch_sim_gather(const float* tokens, const float* mask_f, int B, int L, bf16_t* sel, bf16_t* cls_b, float* cls_f,
-                          hipStream_t st) {
+                          int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "sim_gather");
     SIG_CHECK_ARG(tokens && mask_f && sel && cls_b && cls_f && B > 0 && L > 1, "sim_gather: bad arguments");
     const int rows = 3 * B * (L - 1) + 3 * B;
-    hipLaunchKernelGGL(sim_gather_kernel, dim3(sig_ceil_div(rows, 4)), dim3(256), 0, st, tokens, mask_f, L, B, sel, cls_b, cls_f);
+    hipLaunchKernelGGL(sim_gather_kernel, dim3(sig_ceil_div(rows, 4)), dim3(256), 0, st, tokens, mask_f, L, B, sel, cls_b, cls_f, dt);
     SIG_CHECK_LAUNCH("sim_gather");
     return 0;
 }
 
 int sig_launch_sim_gather_bwd(const bf16_t* dsel, const float* dcls, const float* mask_f, int B, int L, float* dtokens,
-                              hipStream_t st) {
+                              int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "sim_gather_bwd");
     SIG_CHECK_ARG(dsel && dcls && mask_f && dtokens && B > 0 && L > 1, "sim_gather_bwd: bad arguments");
     const int rows = 3 * B * (L - 1) + 3 * B;
-    hipLaunchKernelGGL(sim_gather_bwd_kernel, dim3(sig_ceil_div(rows, 4)), dim3(256), 0, st, dsel, dcls, mask_f, L, B, dtokens);
+    hipLaunchKernelGGL(sim_gather_bwd_kernel, dim3(sig_ceil_div(rows, 4)), dim3(256), 0, st, dsel, dcls, mask_f, L, B, dtokens, dt);
     SIG_CHECK_LAUNCH("sim_gather_bwd");
     return 0;
 }
@@ -281,7 +283,7 @@ int sig_launch_sim_gather_bwd(const bf16_t* dsel, const float* dcls, const float
 #define XA_H 8
 #define XA_MAXK 384
 __global__ __launch_bounds__(512) void xattn_fwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv, int NK,
-                                                        bf16_t* __restrict__ out, float* __restrict__ probs) {
+                                                        bf16_t* __restrict__ out, float* __restrict__ probs, int dt) {
     __shared__ float sq[3 * SIM_D];
     __shared__ float sp[24][XA_MAXK];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(const float* __restrict_
                 const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float k0 = bf2f((bf16_t)(w[e] & 0xffff)), k1 = bf2f((bf16_t)(w[e] >> 16));
+                    const float k0 = cvt16f((bf16_t)(w[e] & 0xffff), dt), k1 = cvt16f((bf16_t)(w[e] >> 16), dt);
                     const int d = h * 64 + c * 8 + e * 2;
                     a0 += k0 * sq[d] + k1 * sq[d + 1];
                     a1 += k0 * sq[SIM_D + d] + k1 * sq[SIM_D + d + 1];
@@ -337,21 +339,21 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(const float* __restrict_
         const bf16_t* vcol = kv + (size_t)b * NK * 1024 + 512 + c;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int j = 0; j < NK; ++j) {
-            const float v = bf2f(vcol[(size_t)j * 1024]);
+            const float v = cvt16f(vcol[(size_t)j * 1024], dt);
             a0 += sp[h * 3 + 0][j] * v;
             a1 += sp[h * 3 + 1][j] * v;
             a2 += sp[h * 3 + 2][j] * v;
         }
-        out[((size_t)b * 3 + 0) * SIM_D + c] = f2bf(a0);
-        out[((size_t)b * 3 + 1) * SIM_D + c] = f2bf(a1);
-        out[((size_t)b * 3 + 2) * SIM_D + c] = f2bf(a2);
+        out[((size_t)b * 3 + 0) * SIM_D + c] = f2cvt16(a0, dt);
+        out[((size_t)b * 3 + 1) * SIM_D + c] = f2cvt16(a1, dt);
+        out[((size_t)b * 3 + 2) * SIM_D + c] = f2cvt16(a2, dt);
     }
 }
 
 // backward: given dout f32 [B*3,512] -> dq f32 [B*3,512], dkv bf16 [B*NK,1024]
 __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
                                                         const float* __restrict__ probs, const float* __restrict__ dout, int NK,
-                                                        float* __restrict__ dq, bf16_t* __restrict__ dkv) {
+                                                        float* __restrict__ dq, bf16_t* __restrict__ dkv, int dt) {
     __shared__ float sq[3 * SIM_D], sdo[3 * SIM_D];
     __shared__ float sp[24][XA_MAXK];   // probs, then dS (scaled)
     __shared__ float sdelta[24];
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict_
         const float d0 = sdo[c], d1 = sdo[SIM_D + c], d2 = sdo[2 * SIM_D + c];
         bf16_t* dv = dkv + (size_t)b * NK * 1024 + 512 + c;
         for (int j = 0; j < NK; ++j)
-            dv[(size_t)j * 1024] = f2bf(sp[h * 3 + 0][j] * d0 + sp[h * 3 + 1][j] * d1 + sp[h * 3 + 2][j] * d2);
+            dv[(size_t)j * 1024] = f2cvt16(sp[h * 3 + 0][j] * d0 + sp[h * 3 + 1][j] * d1 + sp[h * 3 + 2][j] * d2, dt);
     }
     __syncthreads();
     // dP[r][j] = dO[qi, head h] . v[j, head h]; delta[r] = sum_j p dP; dS = p (dP - delta) / 8
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict_
                 const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v0 = bf2f((bf16_t)(w[e] & 0xffff)), v1 = bf2f((bf16_t)(w[e] >> 16));
+                    const float v0 = cvt16f((bf16_t)(w[e] & 0xffff), dt), v1 = cvt16f((bf16_t)(w[e] >> 16), dt);
                     const int d = h * 64 + c * 8 + e * 2;
                     a0 += v0 * sdo[d] + v1 * sdo[d + 1];
                     a1 += v0 * sdo[SIM_D + d] + v1 * sdo[SIM_D + d + 1];
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict_
         const float q0 = sq[c], q1 = sq[SIM_D + c], q2 = sq[2 * SIM_D + c];
         bf16_t* dk = dkv + (size_t)b * NK * 1024 + c;
         for (int j = 0; j < NK; ++j)
-            dk[(size_t)j * 1024] = f2bf(sp[h * 3 + 0][j] * q0 + sp[h * 3 + 1][j] * q1 + sp[h * 3 + 2][j] * q2);
+            dk[(size_t)j * 1024] = f2cvt16(sp[h * 3 + 0][j] * q0 + sp[h * 3 + 1][j] * q1 + sp[h * 3 + 2][j] * q2, dt);
     }
     // dq[qi][c] = sum_j dS[h*3+qi][j] k[j][c]
     {
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict_
         const bf16_t* kcol = kv + (size_t)b * NK * 1024 + c;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int j = 0; j < NK; ++j) {
-            const float k = bf2f(kcol[(size_t)j * 1024]);
+            const float k = cvt16f(kcol[(size_t)j * 1024], dt);
             a0 += sp[h * 3 + 0][j] * k;
             a1 += sp[h * 3 + 1][j] * k;
             a2 += sp[h * 3 + 2][j] * k;
@@ -438,16 +440,18 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict_
     (void)wave;
 }
 
-int sig_launch_xattn_fwd(const float* q, const bf16_t* kv, int B, int NK, bf16_t* out, float* probs, hipStream_t st) {
+int sig_launch_xattn_fwd(const float* q, const bf16_t* kv, int B, int NK, bf16_t* out, float* probs, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "xattn_fwd");
     SIG_CHECK_ARG(q && kv && out && B > 0 && NK > 0 && NK <= XA_MAXK, "xattn_fwd: bad arguments (keys %d, max %d)", NK, XA_MAXK);
-    hipLaunchKernelGGL(xattn_fwd_kernel, dim3(B), dim3(512), 0, st, q, kv, NK, out, probs);
+    hipLaunchKernelGGL(xattn_fwd_kernel, dim3(B), dim3(512), 0, st, q, kv, NK, out, probs, dt);
     SIG_CHECK_LAUNCH("xattn_fwd");
     return 0;
 }
 int sig_launch_xattn_bwd(const float* q, const bf16_t* kv, const float* probs, const float* dout, int B, int NK, float* dq,
-                         bf16_t* dkv, hipStream_t st) {
+                         bf16_t* dkv, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "xattn_bwd");
     SIG_CHECK_ARG(q && kv && probs && dout && dq && dkv && B > 0 && NK > 0 && NK <= XA_MAXK, "xattn_bwd: bad arguments");
-    hipLaunchKernelGGL(xattn_bwd_kernel, dim3(B), dim3(512), 0, st, q, kv, probs, dout, NK, dq, dkv);
+    hipLaunchKernelGGL(xattn_bwd_kernel, dim3(B), dim3(512), 0, st, q, kv, probs, dout, NK, dq, dkv, dt);
     SIG_CHECK_LAUNCH("xattn_bwd");
     return 0;
 }

@@ -18,24 +18,25 @@ static int check_dims(const SigVitDims* d, const char* who) {
     SIG_CHECK_ARG(d->D == d->H * 64 && (d->D & 127) == 0, "%s: width %d must be heads*64 and a multiple of 128", who, d->D);
     SIG_CHECK_ARG(d->F > 0 && (d->F & 127) == 0 && d->out_dim > 0 && (d->out_dim & 127) == 0,
                   "%s: F=%d / out_dim=%d must be multiples of 128", who, d->F, d->out_dim);
+    SIG_CHECK_DT(d->dtype, who);
     return 0;
 }
 
-static SigGemmNT nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K, void* out, int ldo,
+static SigGemmNT nt(int dt, const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K, void* out, int ldo,
                     const float* bias = nullptr, const float* res = nullptr, int ldr = 0, void* aux = nullptr, int ldaux = 0) {
     SigGemmNT p;
     p.A = A; p.lda = lda; p.Bt = Bt; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = ldo;
-    p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0; p.colsum = nullptr;
+    p.bias = bias; p.res = res; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux; p.band = 0; p.colsum = nullptr; p.dt = dt;
     return p;
 }
 static SigGemmNT with_colsum(SigGemmNT p, float* colsum) {
     p.colsum = colsum;
     return p;
 }
-static SigGemmTN tn(const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int Mr, int I, int J, float* out, int ldo) {
+static SigGemmTN tn(int dt, const bf16_t* P, int ldp, const bf16_t* Q, int ldq, int Mr, int I, int J, float* out, int ldo) {
     SigGemmTN p;
     p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.Mr = Mr; p.I = I; p.J = J; p.out = out; p.ldo = ldo;
-    p.split = 0; p.m_chunk = 0; p.ws = nullptr;
+    p.split = 0; p.m_chunk = 0; p.ws = nullptr; p.dt = dt;
     return p;
 }
 
@@ -51,10 +52,11 @@ int sig_embed_fwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedAc
     SIG_CHECK_ARG(patch > 0 && (img_h / patch) * (img_w / patch) == d->L - 1, "embed_fwd: %dx%d / %d does not give %d patches",
                   img_h, img_w, patch, d->L - 1);
     hipStream_t st = (hipStream_t)stream;
+    const int dt = d->dtype;
     const int K = 3 * patch * patch, Mt = d->S * (d->L - 1);
     SIG_CHECK_ARG((K & 63) == 0, "embed_fwd: 3*P*P must be a multiple of 64");
-    RUN(sig_launch_im2col(img, a->patches, d->S, img_h, img_w, patch, st));
-    RUN(sig_launch_gemm_nt(nt(a->patches, K, p->w_conv, K, Mt, d->D, K, a->tok, d->D), SIG_EPI_F32, st));
+    RUN(sig_launch_im2col(img, a->patches, d->S, img_h, img_w, patch, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->patches, K, p->w_conv, K, Mt, d->D, K, a->tok, d->D), SIG_EPI_F32, st));
     RUN(sig_launch_embed_assemble(a->tok, p->class_embedding, p->positional_embedding, p->cv_embed, cam_label, p->sie_coe,
                                   p->ln_w, p->ln_b, a->x0, a->pre_ln, a->mean, a->rstd, d->S, d->B, d->L, d->D, 1e-5f, st));
     return 0;
@@ -67,14 +69,15 @@ int sig_embed_bwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedAc
     SIG_CHECK_ARG(p && a && g && dx0 && scratch_dpre && scratch_dtok, "embed_bwd: null argument");
     SIG_CHECK_ARG(a->pre_ln && a->mean && a->rstd, "embed_bwd: forward ran without saving pre_ln / statistics");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = d->dtype;
     const int M = d->S * d->L, Mt = d->S * (d->L - 1), K = 3 * patch * patch;
     SIG_CHECK_ARG((K & 127) == 0, "embed_bwd: 3*P*P must be a multiple of 128");
     RUN(sig_launch_layernorm_bwd(dx0, 0, a->pre_ln, p->ln_w, a->mean, a->rstd, nullptr, scratch_dpre, nullptr, g->ln_w,
-                                 g->ln_b, M, d->D, st));
+                                 g->ln_b, M, d->D, dt, st));
     RUN(sig_launch_embed_bwd(scratch_dpre, nullptr, scratch_dtok, g->class_embedding, g->positional_embedding,
-                             p->cv_embed ? g->cv_embed : nullptr, cam_label, p->sie_coe, d->S, d->B, d->L, d->D, st));
+                             p->cv_embed ? g->cv_embed : nullptr, cam_label, p->sie_coe, d->S, d->B, d->L, d->D, dt, st));
     // conv1.weight gradient: dW[D, 3PP] += dtok^T patches   (pad rows of both operands are zero)
-    RUN(sig_launch_gemm_tn(tn(scratch_dtok, d->D, a->patches, K, pad128(Mt), d->D, K, g->w_conv, K), st));
+    RUN(sig_launch_gemm_tn(tn(dt, scratch_dtok, d->D, a->patches, K, pad128(Mt), d->D, K, g->w_conv, K), st));
     return 0;
 }
 
@@ -86,14 +89,15 @@ int sig_block_fwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
     SIG_CHECK_ARG(p && a, "block_fwd: null argument");
     SIG_CHECK_ARG(a->x_in && a->h1 && a->qkv && a->attn && a->x_mid && a->h2 && a->g && a->x_out, "block_fwd: activation buffer missing");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = d->dtype;
     const int M = d->S * d->L, D = d->D, F = d->F;
-    RUN(sig_launch_layernorm_fwd(a->x_in, p->ln1_w, p->ln1_b, a->h1, nullptr, a->mean1, a->rstd1, M, D, 1e-5f, st));
-    RUN(sig_launch_gemm_nt(nt(a->h1, D, p->w_in, D, M, 3 * D, D, a->qkv, 3 * D, p->b_in), SIG_EPI_BIAS_BF16, st));
-    RUN(sig_launch_attn_fwd(a->qkv, a->attn, a->lse, d->S, d->L, d->H, st));
-    RUN(sig_launch_gemm_nt(nt(a->attn, D, p->w_out, D, M, D, D, a->x_mid, D, p->b_out, a->x_in, D), SIG_EPI_BIAS_RES_F32, st));
-    RUN(sig_launch_layernorm_fwd(a->x_mid, p->ln2_w, p->ln2_b, a->h2, nullptr, a->mean2, a->rstd2, M, D, 1e-5f, st));
-    RUN(sig_launch_gemm_nt(nt(a->h2, D, p->w_fc, D, M, F, D, a->g, F, p->b_fc, nullptr, 0, a->u, F), SIG_EPI_BIAS_GELU_BF16, st));
-    RUN(sig_launch_gemm_nt(nt(a->g, F, p->w_proj, F, M, D, F, a->x_out, D, p->b_proj, a->x_mid, D), SIG_EPI_BIAS_RES_F32, st));
+    RUN(sig_launch_layernorm_fwd(a->x_in, p->ln1_w, p->ln1_b, a->h1, nullptr, a->mean1, a->rstd1, M, D, 1e-5f, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->h1, D, p->w_in, D, M, 3 * D, D, a->qkv, 3 * D, p->b_in), SIG_EPI_BIAS_BF16, st));
+    RUN(sig_launch_attn_fwd(a->qkv, a->attn, a->lse, d->S, d->L, d->H, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->attn, D, p->w_out, D, M, D, D, a->x_mid, D, p->b_out, a->x_in, D), SIG_EPI_BIAS_RES_F32, st));
+    RUN(sig_launch_layernorm_fwd(a->x_mid, p->ln2_w, p->ln2_b, a->h2, nullptr, a->mean2, a->rstd2, M, D, 1e-5f, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->h2, D, p->w_fc, D, M, F, D, a->g, F, p->b_fc, nullptr, 0, a->u, F), SIG_EPI_BIAS_GELU_BF16, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->g, F, p->w_proj, F, M, D, F, a->x_out, D, p->b_proj, a->x_mid, D), SIG_EPI_BIAS_RES_F32, st));
     return 0;
 }
 
@@ -106,32 +110,33 @@ int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
     SIG_CHECK_ARG(a->u && a->lse && a->mean1 && a->rstd1 && a->mean2 && a->rstd2, "block_bwd: forward ran without saving for backward");
     SIG_CHECK_ARG(s->du && s->dh && s->dqkv && s->dx_mid && s->dx_mid_b, "block_bwd: scratch missing");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = d->dtype;
     const int M = d->S * d->L, Mp = pad128(M), D = d->D, F = d->F;
     // Bias gradients are by-products of kernels that already hold the data: c_fc bias from the dGELU epilogue, out_proj
     // bias from LN2's backward (column sums of dx_mid), and c_proj bias =
     // column sums of dx_out, which the stage ABOVE accumulates when it writes dx_out (b_proj_done) -- else a pass here.
     // ---- MLP ----
-    RUN(sig_launch_gemm_nt(with_colsum(nt(dx_out_b, D, p->wt_proj, D, M, F, D, s->du, F, nullptr, nullptr, 0, a->u, F), g->b_fc),
+    RUN(sig_launch_gemm_nt(with_colsum(nt(dt, dx_out_b, D, p->wt_proj, D, M, F, D, s->du, F, nullptr, nullptr, 0, a->u, F), g->b_fc),
                            SIG_EPI_DGELU_BF16, st));                                              // du = (dx_out W_proj) * QuickGELU'(u)
-    RUN(sig_launch_gemm_tn(tn(dx_out_b, D, a->g, F, Mp, D, F, g->w_proj, F), st));
-    if (!b_proj_done) RUN(sig_launch_colsum_bf16(dx_out_b, D, M, D, g->b_proj, st));
-    RUN(sig_launch_gemm_nt(nt(s->du, F, p->wt_fc, F, M, D, F, s->dh, D), SIG_EPI_BF16, st));     // dh2 = du W_fc
-    RUN(sig_launch_gemm_tn(tn(s->du, F, a->h2, D, Mp, F, D, g->w_fc, D), st));
+    RUN(sig_launch_gemm_tn(tn(dt, dx_out_b, D, a->g, F, Mp, D, F, g->w_proj, F), st));
+    if (!b_proj_done) RUN(sig_launch_colsum_bf16(dx_out_b, D, M, D, g->b_proj, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, s->du, F, p->wt_fc, F, M, D, F, s->dh, D), SIG_EPI_BF16, st));     // dh2 = du W_fc
+    RUN(sig_launch_gemm_tn(tn(dt, s->du, F, a->h2, D, Mp, F, D, g->w_fc, D), st));
     // dx_mid = dx_out + LN2'(dh2)
     RUN(sig_launch_layernorm_bwd(s->dh, 1, a->x_mid, p->ln2_w, a->mean2, a->rstd2, dx_out, s->dx_mid, s->dx_mid_b, g->ln2_w,
-                                 g->ln2_b, M, D, st, g->b_out));
+                                 g->ln2_b, M, D, dt, st, g->b_out));
     // ---- attention ----
-    RUN(sig_launch_gemm_nt(nt(s->dx_mid_b, D, p->wt_out, D, M, D, D, s->dh, D), SIG_EPI_BF16, st));  // d attn
-    RUN(sig_launch_gemm_tn(tn(s->dx_mid_b, D, a->attn, D, Mp, D, D, g->w_out, D), st));
+    RUN(sig_launch_gemm_nt(nt(dt, s->dx_mid_b, D, p->wt_out, D, M, D, D, s->dh, D), SIG_EPI_BF16, st));  // d attn
+    RUN(sig_launch_gemm_tn(tn(dt, s->dx_mid_b, D, a->attn, D, Mp, D, D, g->w_out, D), st));
     // (in_proj bias: every (sequence) workgroup of a head would hit the same 192 addresses -- measured 2x slower with
     //  in-kernel atomics -- so it stays a separate 25 us column-sum pass over dqkv)
-    RUN(sig_launch_attn_bwd(a->qkv, a->attn, s->dh, a->lse, s->dqkv, d->S, d->L, d->H, st));
-    RUN(sig_launch_colsum_bf16(s->dqkv, 3 * D, M, 3 * D, g->b_in, st));
-    RUN(sig_launch_gemm_nt(nt(s->dqkv, 3 * D, p->wt_in, 3 * D, M, D, 3 * D, s->dh, D), SIG_EPI_BF16, st));  // dh1
-    RUN(sig_launch_gemm_tn(tn(s->dqkv, 3 * D, a->h1, D, Mp, 3 * D, D, g->w_in, D), st));
+    RUN(sig_launch_attn_bwd(a->qkv, a->attn, s->dh, a->lse, s->dqkv, d->S, d->L, d->H, dt, st));
+    RUN(sig_launch_colsum_bf16(s->dqkv, 3 * D, M, 3 * D, g->b_in, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, s->dqkv, 3 * D, p->wt_in, 3 * D, M, D, 3 * D, s->dh, D), SIG_EPI_BF16, st));  // dh1
+    RUN(sig_launch_gemm_tn(tn(dt, s->dqkv, 3 * D, a->h1, D, Mp, 3 * D, D, g->w_in, D), st));
     // dx_in = dx_mid + LN1'(dh1)
     RUN(sig_launch_layernorm_bwd(s->dh, 1, a->x_in, p->ln1_w, a->mean1, a->rstd1, s->dx_mid, dx_in, dx_in_b, g->ln1_w, g->ln1_b,
-                                 M, D, st, dx_in_colsum));
+                                 M, D, dt, st, dx_in_colsum));
     return 0;
 }
 
@@ -142,9 +147,10 @@ int sig_head_fwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs*
     RUN(check_dims(d, "head_fwd"));
     SIG_CHECK_ARG(p && a && a->x && a->hp && a->tokens && p->proj_t, "head_fwd: null argument");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = d->dtype;
     const int M = d->S * d->L;
-    RUN(sig_launch_layernorm_fwd(a->x, p->ln_w, p->ln_b, a->hp, nullptr, a->mean, a->rstd, M, d->D, 1e-5f, st));
-    RUN(sig_launch_gemm_nt(nt(a->hp, d->D, p->proj_t, d->D, M, d->out_dim, d->D, a->tokens, d->out_dim), SIG_EPI_F32, st));
+    RUN(sig_launch_layernorm_fwd(a->x, p->ln_w, p->ln_b, a->hp, nullptr, a->mean, a->rstd, M, d->D, 1e-5f, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->hp, d->D, p->proj_t, d->D, M, d->out_dim, d->D, a->tokens, d->out_dim), SIG_EPI_F32, st));
     return 0;
 }
 
@@ -155,11 +161,12 @@ int sig_head_bwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs*
     SIG_CHECK_ARG(p && a && g && dtokens && scratch_dtok_b && scratch_dh && dx && dx_b && p->proj, "head_bwd: null argument");
     SIG_CHECK_ARG(a->mean && a->rstd, "head_bwd: forward ran without saving statistics");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = d->dtype;
     const int M = d->S * d->L, Mp = pad128(M), D = d->D, O = d->out_dim;
-    RUN(sig_launch_cast_bf16(dtokens, scratch_dtok_b, (size_t)Mp * O, st));
-    RUN(sig_launch_gemm_nt(nt(scratch_dtok_b, O, p->proj, O, M, D, O, scratch_dh, D), SIG_EPI_BF16, st));  // d ln_post out
-    RUN(sig_launch_gemm_tn(tn(a->hp, D, scratch_dtok_b, O, Mp, D, O, g->proj, O), st));                    // d proj [D,O]
-    RUN(sig_launch_layernorm_bwd(scratch_dh, 1, a->x, p->ln_w, a->mean, a->rstd, nullptr, dx, dx_b, g->ln_w, g->ln_b, M, D, st, dx_colsum));
+    RUN(sig_launch_cast_bf16(dtokens, scratch_dtok_b, (size_t)Mp * O, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, scratch_dtok_b, O, p->proj, O, M, D, O, scratch_dh, D), SIG_EPI_BF16, st));  // d ln_post out
+    RUN(sig_launch_gemm_tn(tn(dt, a->hp, D, scratch_dtok_b, O, Mp, D, O, g->proj, O), st));                    // d proj [D,O]
+    RUN(sig_launch_layernorm_bwd(scratch_dh, 1, a->x, p->ln_w, a->mean, a->rstd, nullptr, dx, dx_b, g->ln_w, g->ln_b, M, D, dt, st, dx_colsum));
     return 0;
 }
 
@@ -177,17 +184,18 @@ int sig_sim_fwd(const float* tokens, int B, int L, const SigSimParams* p, const 
     SIG_CHECK_ARG(a->sel && a->cls_b && a->cls_f && a->qh && a->kv && a->ao && a->y && a->z1 && a->z1_b && a->f1 && a->y2 && a->out,
                   "sim_fwd: activation buffer missing");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = p->dtype;
     const int Mq = 3 * B, Mk = 3 * B * (L - 1), d = 512;
-    RUN(sig_launch_sim_gather(tokens, a->mask_f, B, L, a->sel, a->cls_b, a->cls_f, st));
-    RUN(sig_launch_gemm_nt(nt(a->cls_b, d, p->w_q, d, Mq, d, d, a->qh, d, p->b_q), SIG_EPI_BIAS_F32, st));
-    RUN(sig_launch_gemm_nt(nt(a->sel, d, p->w_kv, d, Mk, 2 * d, d, a->kv, 2 * d, p->b_kv), SIG_EPI_BIAS_BF16, st));
-    RUN(sig_launch_xattn_fwd(a->qh, a->kv, B, 3 * (L - 1), a->ao, a->probs, st));
-    RUN(sig_launch_gemm_nt(nt(a->ao, d, p->w_o, d, Mq, d, d, a->y, d, p->b_o, a->cls_f, d), SIG_EPI_BIAS_RES_F32, st));
-    RUN(sig_launch_layernorm_fwd(a->y, p->n1_w, p->n1_b, a->z1_b, a->z1, a->mean1, a->rstd1, Mq, d, 1e-5f, st));
-    RUN(sig_launch_gemm_nt(nt(a->z1_b, d, p->w_f1, d, Mq, 2 * d, d, a->f1, 2 * d, p->b_f1, nullptr, 0, a->f1_pre, 2 * d),
+    RUN(sig_launch_sim_gather(tokens, a->mask_f, B, L, a->sel, a->cls_b, a->cls_f, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->cls_b, d, p->w_q, d, Mq, d, d, a->qh, d, p->b_q), SIG_EPI_BIAS_F32, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->sel, d, p->w_kv, d, Mk, 2 * d, d, a->kv, 2 * d, p->b_kv), SIG_EPI_BIAS_BF16, st));
+    RUN(sig_launch_xattn_fwd(a->qh, a->kv, B, 3 * (L - 1), a->ao, a->probs, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->ao, d, p->w_o, d, Mq, d, d, a->y, d, p->b_o, a->cls_f, d), SIG_EPI_BIAS_RES_F32, st));
+    RUN(sig_launch_layernorm_fwd(a->y, p->n1_w, p->n1_b, a->z1_b, a->z1, a->mean1, a->rstd1, Mq, d, 1e-5f, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->z1_b, d, p->w_f1, d, Mq, 2 * d, d, a->f1, 2 * d, p->b_f1, nullptr, 0, a->f1_pre, 2 * d),
                            SIG_EPI_BIAS_GELUERF_BF16, st));
-    RUN(sig_launch_gemm_nt(nt(a->f1, 2 * d, p->w_f2, 2 * d, Mq, d, 2 * d, a->y2, d, p->b_f2, a->z1, d), SIG_EPI_BIAS_RES_F32, st));
-    RUN(sig_launch_layernorm_fwd(a->y2, p->n2_w, p->n2_b, nullptr, a->out, a->mean2, a->rstd2, Mq, d, 1e-5f, st));
+    RUN(sig_launch_gemm_nt(nt(dt, a->f1, 2 * d, p->w_f2, 2 * d, Mq, d, 2 * d, a->y2, d, p->b_f2, a->z1, d), SIG_EPI_BIAS_RES_F32, st));
+    RUN(sig_launch_layernorm_fwd(a->y2, p->n2_w, p->n2_b, nullptr, a->out, a->mean2, a->rstd2, Mq, d, 1e-5f, dt, st));
     return 0;
 }
 
@@ -197,36 +205,37 @@ int sig_sim_bwd(const float* dout, int B, int L, const SigSimParams* p, const Si
     SIG_CHECK_ARG(p->wt_q && p->wt_kv && p->wt_o && p->wt_f1 && p->wt_f2, "sim_bwd: transposed weights missing");
     SIG_CHECK_ARG(a->probs && a->f1_pre && a->mean1 && a->rstd1 && a->mean2 && a->rstd2, "sim_bwd: forward ran without saving for backward");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = p->dtype;
     const int Mq = 3 * B, Mqp = pad128(Mq), Mk = 3 * B * (L - 1), Mkp = pad128(Mk), d = 512;
     // norm2
-    RUN(sig_launch_layernorm_bwd(dout, 0, a->y2, p->n2_w, a->mean2, a->rstd2, nullptr, s->dy2, s->dy2_b, g->n2_w, g->n2_b, Mq, d, st));
+    RUN(sig_launch_layernorm_bwd(dout, 0, a->y2, p->n2_w, a->mean2, a->rstd2, nullptr, s->dy2, s->dy2_b, g->n2_w, g->n2_b, Mq, d, dt, st));
     // ffn.2 (+ residual into z1)
-    RUN(sig_launch_gemm_nt(nt(s->dy2_b, d, p->wt_f2, d, Mq, 2 * d, d, s->df1, 2 * d, nullptr, nullptr, 0, a->f1_pre, 2 * d), SIG_EPI_DGELUERF_BF16, st));
-    RUN(sig_launch_gemm_tn(tn(s->dy2_b, d, a->f1, 2 * d, Mqp, d, 2 * d, g->w_f2, 2 * d), st));
+    RUN(sig_launch_gemm_nt(nt(dt, s->dy2_b, d, p->wt_f2, d, Mq, 2 * d, d, s->df1, 2 * d, nullptr, nullptr, 0, a->f1_pre, 2 * d), SIG_EPI_DGELUERF_BF16, st));
+    RUN(sig_launch_gemm_tn(tn(dt, s->dy2_b, d, a->f1, 2 * d, Mqp, d, 2 * d, g->w_f2, 2 * d), st));
     RUN(sig_launch_colsum_f32(s->dy2, d, Mq, d, g->b_f2, st));
     // ffn.0 ; total gradient of z1 = dy2 (residual) + df1 W_f1
-    RUN(sig_launch_gemm_nt(nt(s->df1, 2 * d, p->wt_f1, 2 * d, Mq, d, 2 * d, s->dz1, d, nullptr, s->dy2, d), SIG_EPI_RES_F32, st));
-    RUN(sig_launch_gemm_tn(tn(s->df1, 2 * d, a->z1_b, d, Mqp, 2 * d, d, g->w_f1, d), st));
-    RUN(sig_launch_colsum_bf16(s->df1, 2 * d, Mq, 2 * d, g->b_f1, st));
+    RUN(sig_launch_gemm_nt(nt(dt, s->df1, 2 * d, p->wt_f1, 2 * d, Mq, d, 2 * d, s->dz1, d, nullptr, s->dy2, d), SIG_EPI_RES_F32, st));
+    RUN(sig_launch_gemm_tn(tn(dt, s->df1, 2 * d, a->z1_b, d, Mqp, 2 * d, d, g->w_f1, d), st));
+    RUN(sig_launch_colsum_bf16(s->df1, 2 * d, Mq, 2 * d, g->b_f1, dt, st));
     // norm1
-    RUN(sig_launch_layernorm_bwd(s->dz1, 0, a->y, p->n1_w, a->mean1, a->rstd1, nullptr, s->dy, s->dy_b, g->n1_w, g->n1_b, Mq, d, st));
+    RUN(sig_launch_layernorm_bwd(s->dz1, 0, a->y, p->n1_w, a->mean1, a->rstd1, nullptr, s->dy, s->dy_b, g->n1_w, g->n1_b, Mq, d, dt, st));
     // out_proj
-    RUN(sig_launch_gemm_nt(nt(s->dy_b, d, p->wt_o, d, Mq, d, d, s->dao, d), SIG_EPI_F32, st));
-    RUN(sig_launch_gemm_tn(tn(s->dy_b, d, a->ao, d, Mqp, d, d, g->w_o, d), st));
+    RUN(sig_launch_gemm_nt(nt(dt, s->dy_b, d, p->wt_o, d, Mq, d, d, s->dao, d), SIG_EPI_F32, st));
+    RUN(sig_launch_gemm_tn(tn(dt, s->dy_b, d, a->ao, d, Mqp, d, d, g->w_o, d), st));
     RUN(sig_launch_colsum_f32(s->dy, d, Mq, d, g->b_o, st));
     // attention core
-    RUN(sig_launch_xattn_bwd(a->qh, a->kv, a->probs, s->dao, B, 3 * (L - 1), s->dqh, s->dkv, st));
+    RUN(sig_launch_xattn_bwd(a->qh, a->kv, a->probs, s->dao, B, 3 * (L - 1), s->dqh, s->dkv, dt, st));
     // k|v projection
-    RUN(sig_launch_gemm_nt(nt(s->dkv, 2 * d, p->wt_kv, 2 * d, Mk, d, 2 * d, s->dsel, d), SIG_EPI_BF16, st));
-    RUN(sig_launch_gemm_tn(tn(s->dkv, 2 * d, a->sel, d, Mkp, 2 * d, d, g->w_kv, d), st));
-    RUN(sig_launch_colsum_bf16(s->dkv, 2 * d, Mk, 2 * d, g->b_kv, st));
+    RUN(sig_launch_gemm_nt(nt(dt, s->dkv, 2 * d, p->wt_kv, 2 * d, Mk, d, 2 * d, s->dsel, d), SIG_EPI_BF16, st));
+    RUN(sig_launch_gemm_tn(tn(dt, s->dkv, 2 * d, a->sel, d, Mkp, 2 * d, d, g->w_kv, d), st));
+    RUN(sig_launch_colsum_bf16(s->dkv, 2 * d, Mk, 2 * d, g->b_kv, dt, st));
     // q projection ; total gradient of the stacked CLS = dy (residual) + dqh W_q
-    RUN(sig_launch_cast_bf16(s->dqh, s->dqh_b, (size_t)Mqp * d, st));
-    RUN(sig_launch_gemm_nt(nt(s->dqh_b, d, p->wt_q, d, Mq, d, d, s->dcls, d, nullptr, s->dy, d), SIG_EPI_RES_F32, st));
-    RUN(sig_launch_gemm_tn(tn(s->dqh_b, d, a->cls_b, d, Mqp, d, d, g->w_q, d), st));
+    RUN(sig_launch_cast_bf16(s->dqh, s->dqh_b, (size_t)Mqp * d, dt, st));
+    RUN(sig_launch_gemm_nt(nt(dt, s->dqh_b, d, p->wt_q, d, Mq, d, d, s->dcls, d, nullptr, s->dy, d), SIG_EPI_RES_F32, st));
+    RUN(sig_launch_gemm_tn(tn(dt, s->dqh_b, d, a->cls_b, d, Mqp, d, d, g->w_q, d), st));
     RUN(sig_launch_colsum_f32(s->dqh, d, Mq, d, g->b_q, st));
     // scatter back to the token gradient
-    RUN(sig_launch_sim_gather_bwd(s->dsel, s->dcls, a->mask_f, B, L, dtokens, st));
+    RUN(sig_launch_sim_gather_bwd(s->dsel, s->dcls, a->mask_f, B, L, dtokens, dt, st));
     return 0;
 }
 
@@ -242,30 +251,32 @@ int sig_gam_bwd(int B, int L, const SigGamActs* a, const float* dloss, float* dt
     return sig_launch_gam_bwd(a->fh, a->nrm, a->coef, dloss, B, L, dtokens, d_contra_temp, (hipStream_t)stream);
 }
 
-int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, const SigDasParams* p3, const SigLamActs* a, void* stream) {
+int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, int dtype, const SigDasParams* p3, const SigLamActs* a, void* stream) {
     SIG_CHECK_ARG(tokens && p3 && a, "lam_fwd: null argument");
     SIG_CHECK_ARG(a->xb && a->q && a->a1 && a->a1pre && a->a2pre && a->offs && a->samp && a->loss, "lam_fwd: activation buffer missing");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = dtype;
     const int R = B * (L - 1), Rp = pad128(R), d = 512, P = (h / 4) * (w / 4);
-    RUN(sig_launch_lam_gather(tokens, B, L, a->xb, (size_t)Rp, st));
+    RUN(sig_launch_lam_gather(tokens, B, L, a->xb, (size_t)Rp, dt, st));
     for (int m = 0; m < 3; ++m) {
         const SigDasParams* p = p3 + m;
         const size_t o = (size_t)m * Rp * d;
-        RUN(sig_launch_gemm_nt(nt(a->xb + o, d, p->w_q, d, R, d, d, a->q + o, d, p->b_q), SIG_EPI_BIAS_BF16, st));
-        RUN(sig_launch_gemm_nt(nt(a->q + o, d, p->w_0, d, R, d, d, a->a1 + o, d, p->b_0, nullptr, 0, a->a1pre + o, d),
+        RUN(sig_launch_gemm_nt(nt(dt, a->xb + o, d, p->w_q, d, R, d, d, a->q + o, d, p->b_q), SIG_EPI_BIAS_BF16, st));
+        RUN(sig_launch_gemm_nt(nt(dt, a->q + o, d, p->w_0, d, R, d, d, a->a1 + o, d, p->b_0, nullptr, 0, a->a1pre + o, d),
                                SIG_EPI_BIAS_GELUERF_BF16, st));
         RUN(sig_launch_lam_tail_fwd(tokens, m, B, L, h, w, a->a1 + o, p->wd, p->bd, p->w4, a->a2pre + (size_t)m * B * P * d,
-                                    a->offs + (size_t)m * B * P * 3, a->samp + (size_t)m * B * P * d, st));
+                                    a->offs + (size_t)m * B * P * 3, a->samp + (size_t)m * B * P * d, dt, st));
     }
     RUN(sig_launch_lam_loss(a->samp, (size_t)B * P * d, a->loss, st));
     return 0;
 }
 
-int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, const SigDasParams* p3, const SigDasGrads* g3,
+int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, int dtype, const SigDasParams* p3, const SigDasGrads* g3,
                 const SigLamActs* a, const SigLamScratch* s, const float* dloss, float* dtokens, void* stream) {
     SIG_CHECK_ARG(tokens && p3 && g3 && a && s && dloss && dtokens, "lam_bwd: null argument");
     SIG_CHECK_ARG(s->da1pre && s->dq && s->dx, "lam_bwd: scratch missing");
     hipStream_t st = (hipStream_t)stream;
+    const int dt = dtype;
     const int R = B * (L - 1), Rp = pad128(R), d = 512, P = (h / 4) * (w / 4);
     const size_t nsamp = (size_t)B * P * d;
     for (int m = 0; m < 3; ++m) {
@@ -274,27 +285,27 @@ int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, const SigDasPar
         SIG_CHECK_ARG(p->wt_q && p->wt_0, "lam_bwd: transposed weights missing");
         const size_t o = (size_t)m * Rp * d;
         RUN(sig_launch_lam_tail_bwd(tokens, m, B, L, h, w, a->a1 + o, a->a1pre + o, p->wd, p->w4, a->a2pre + (size_t)m * nsamp,
-                                    a->offs + (size_t)m * B * P * 3, a->samp, nsamp, dloss, s->da1pre, g->wd, g->bd, g->w4, dtokens, st,
+                                    a->offs + (size_t)m * B * P * 3, a->samp, nsamp, dloss, s->da1pre, g->wd, g->bd, g->w4, dtokens, dt, st,
                                     (size_t)B * 18 * d <= (size_t)Rp * d ? s->dx : nullptr));   // dx is free until the proj_q dgrad below
         // conv_offset.0
-        RUN(sig_launch_gemm_nt(nt(s->da1pre, d, p->wt_0, d, R, d, d, s->dq, d), SIG_EPI_BF16, st));
-        RUN(sig_launch_gemm_tn(tn(s->da1pre, d, a->q + o, d, Rp, d, d, g->w_0, d), st));
-        RUN(sig_launch_colsum_bf16(s->da1pre, d, R, d, g->b_0, st));
+        RUN(sig_launch_gemm_nt(nt(dt, s->da1pre, d, p->wt_0, d, R, d, d, s->dq, d), SIG_EPI_BF16, st));
+        RUN(sig_launch_gemm_tn(tn(dt, s->da1pre, d, a->q + o, d, Rp, d, d, g->w_0, d), st));
+        RUN(sig_launch_colsum_bf16(s->da1pre, d, R, d, g->b_0, dt, st));
         // proj_q
-        RUN(sig_launch_gemm_nt(nt(s->dq, d, p->wt_q, d, R, d, d, s->dx, d), SIG_EPI_F32, st));
-        RUN(sig_launch_gemm_tn(tn(s->dq, d, a->xb + o, d, Rp, d, d, g->w_q, d), st));
-        RUN(sig_launch_colsum_bf16(s->dq, d, R, d, g->b_q, st));
+        RUN(sig_launch_gemm_nt(nt(dt, s->dq, d, p->wt_q, d, R, d, d, s->dx, d), SIG_EPI_F32, st));
+        RUN(sig_launch_gemm_tn(tn(dt, s->dq, d, a->xb + o, d, Rp, d, d, g->w_q, d), st));
+        RUN(sig_launch_colsum_bf16(s->dq, d, R, d, g->b_q, dt, st));
         RUN(sig_launch_lam_scatter_add(s->dx, m, B, L, dtokens, st));
     }
     return 0;
 }
 
-int sig_xattn_fwd(const float* q, const uint16_t* kv, int B, int NK, uint16_t* out, float* probs, void* stream) {
-    return sig_launch_xattn_fwd(q, kv, B, NK, out, probs, (hipStream_t)stream);
+int sig_xattn_fwd(const float* q, const uint16_t* kv, int B, int NK, uint16_t* out, float* probs, int dtype, void* stream) {
+    return sig_launch_xattn_fwd(q, kv, B, NK, out, probs, dtype, (hipStream_t)stream);
 }
 int sig_xattn_bwd(const float* q, const uint16_t* kv, const float* probs, const float* dout, int B, int NK, float* dq,
-                  uint16_t* dkv, void* stream) {
-    return sig_launch_xattn_bwd(q, kv, probs, dout, B, NK, dq, dkv, (hipStream_t)stream);
+                  uint16_t* dkv, int dtype, void* stream) {
+    return sig_launch_xattn_bwd(q, kv, probs, dout, B, NK, dq, dkv, dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -14,8 +14,9 @@ from .. import _lib
 from .._lib import fill, ref
 from ..ops import pad_rows
 
-BF = torch.bfloat16
 F32 = torch.float32
+OPERAND_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16,
+                  "float16": torch.float16, "half": torch.float16}
 
 
 def _stream() -> int:
@@ -24,10 +25,10 @@ def _stream() -> int:
 
 class FlatParams:
     """All parameters the HIP stages read live in ONE f32 buffer (views are re-pointed into it), their
-    gradients in one f32 buffer of the same layout, and the bf16 operands of the GEMMs in one bf16
-    buffer: packing is one cast kernel over the whole buffer plus one transpose per matrix."""
+    gradients in one f32 buffer of the same layout, and the 16-bit operands of the GEMMs (bf16 or f16, `op16`) in
+    one buffer of that type: packing is one cast kernel over the whole buffer plus one transpose per matrix."""
 
-    def __init__(self, named: Dict[str, torch.nn.Parameter], device):
+    def __init__(self, named: Dict[str, torch.nn.Parameter], device, op_dtype=torch.bfloat16):
         self.names = list(named)
         self.params = [named[n] for n in self.names]
         self.offsets, off = {}, 0
@@ -38,7 +39,7 @@ class FlatParams:
         self.device = device
         self.data = torch.zeros(off, dtype=F32, device=device)
         self.grad = torch.zeros(off, dtype=F32, device=device)
-        self.bf16 = torch.zeros(off, dtype=BF, device=device)
+        self.op16 = torch.zeros(off, dtype=op_dtype, device=device)
         with torch.no_grad():
             for n, p in zip(self.names, self.params):
                 v = self.view(self.data, n, p.shape)
@@ -96,6 +97,23 @@ class _Ws:
         return t
 
 
+class _WsLease:
+    """Hands a workspace back to its pool exactly once: explicitly when the backward has consumed it, or when the autograd
+    node holding the lease is dropped without a backward (a forward under grad mode that is never differentiated, an
+    exception between forward and backward) -- such a call used to strand a multi-GB training workspace per occurrence."""
+    __slots__ = ("ws",)
+
+    def __init__(self, ws):
+        self.ws = ws          # ws["_free"] is the pool's free list (no reference cycle: the workspace does not know the lease)
+
+    def release(self):
+        ws, self.ws = self.ws, None
+        if ws is not None:
+            ws["_free"].append(ws)
+
+    __del__ = release
+
+
 class HipPath:
     def __init__(self, model):
         self.model = model
@@ -108,6 +126,14 @@ class HipPath:
         b = enc.base
         self.D, self.H, self.layers, self.out_dim, self.patch = b.width, b.heads, b.layers, b.output_dim, b.patch
         self.F = 4 * self.D
+        import os
+        name = os.environ.get("SIGNAL_HIP_DTYPE") or getattr(model.cfg.MODEL, "OPERAND_DTYPE", "bf16")
+        if str(name).lower() not in OPERAND_DTYPES:
+            raise ValueError(f"MODEL.OPERAND_DTYPE={name!r}: expected 'bf16' or 'fp16'")
+        # MFMA operand type of every GEMM / attention (f32 accumulate, residual stream, LayerNorm, softmax either way):
+        # bf16, or fp16 = the reference's CUDA autocast type (engine/processor.py:165), trained with loss scaling
+        self.operand_dtype = OPERAND_DTYPES[str(name).lower()]
+        self.dt = 1 if self.operand_dtype == torch.float16 else 0
         self.L = b.h_resolution * b.w_resolution + 1
         self.img_hw = (b.h_resolution * b.patch, b.w_resolution * b.patch)
 
@@ -127,7 +153,7 @@ class HipPath:
             named = self._hip_named_params()
             if any(p.device != device for p in named.values()):
                 raise _lib.SignalHipError("model parameters are not on the input's device: call model.to(device) first")
-            self.flat = FlatParams(named, device)
+            self.flat = FlatParams(named, device, self.operand_dtype)
             self._build_structs()
             if self.direct_grads:
                 self.enable_direct_grads()
@@ -140,21 +166,28 @@ class HipPath:
     # here right before .apply(); without it an inference forward took (and never returned) a training workspace.
     grad_mode = True
 
-    def enable_direct_grads(self):
+    _grad_skip = None
+
+    def enable_direct_grads(self, skip=None):
         """Training-engine mode: every Parameter's .grad is a persistent view of flat.grad; the HIP backward
         stages accumulate straight into it (no per-step clone), zeroing is one memset, the optimizer and the
-        data-parallel reducer work on the flat buffer."""
+        data-parallel reducer work on the flat buffer.  Parameters that can never receive a gradient (skip(name) true,
+        or requires_grad False) keep .grad = None -- what autograd leaves them with in the reference -- so that torch
+        optimizers skip them instead of applying weight decay to a zero gradient."""
         self.direct_grads = True
+        if skip is not None:
+            self._grad_skip = skip
+        skip = self._grad_skip or (lambda n: False)
         for n, p in self.flat.byname.items():
-            p.grad = self.flat.view(self.flat.grad, n)
+            p.grad = None if (skip(n) or not p.requires_grad) else self.flat.view(self.flat.grad, n)
 
     def after_fused_step(self):
-        """The fused optimizer already refreshed flat.bf16; redo the transposed copies and mark versions."""
+        """The fused optimizer already refreshed flat.op16; redo the transposed copies and mark versions."""
         self._pack(cast=False)
         self.flat._versions = tuple(p._version for p in self.flat.params)
 
-    def _pk(self, name):      # bf16 view of a parameter (same layout as f32)
-        return self.flat.view(self.flat.bf16, name)
+    def _pk(self, name):      # 16-bit operand view of a parameter (same layout as f32)
+        return self.flat.view(self.flat.op16, name)
 
     def _g(self, name):       # f32 gradient view
         return self.flat.view(self.flat.grad, name)
@@ -185,7 +218,7 @@ class HipPath:
         self._tt = None
 
         def T(name, rows, cols):   # storage for the transposed bf16 copy of a [rows, cols] matrix
-            t = torch.zeros(cols, rows, dtype=BF, device=dev)
+            t = torch.zeros(cols, rows, dtype=self.operand_dtype, device=dev)
             self._transposed[name] = t
             return t
 
@@ -233,7 +266,8 @@ class HipPath:
             inw, inb = mi + "cross_attn.in_proj_weight", mi + "cross_attn.in_proj_bias"
             w_in_bf, g_in = self._pk(inw), self._g(inw)
             b_in, gb_in = self._p(inb), self._g(inb)
-            self._sim_T = dict(q=torch.zeros(d, d, dtype=BF, device=dev), kv=torch.zeros(d, 2 * d, dtype=BF, device=dev))
+            self._sim_T = dict(q=torch.zeros(d, d, dtype=self.operand_dtype, device=dev),
+                               kv=torch.zeros(d, 2 * d, dtype=self.operand_dtype, device=dev))
             self.sim_p = fill(
                 _lib.SigSimParams, sel_wq=self._p(s + "W_q.weight"), sel_bq=self._p(s + "W_q.bias"),
                 sel_wk=self._p(s + "W_k.weight"), sel_bk=self._p(s + "W_k.bias"),
@@ -244,7 +278,8 @@ class HipPath:
                 b_q=b_in[:d], b_kv=b_in[d:], b_o=self._p(mi + "cross_attn.out_proj.bias"),
                 b_f1=self._p(mi + "ffn.0.bias"), b_f2=self._p(mi + "ffn.2.bias"),
                 n1_w=self._p(mi + "norm1.weight"), n1_b=self._p(mi + "norm1.bias"),
-                n2_w=self._p(mi + "norm2.weight"), n2_b=self._p(mi + "norm2.bias"), topk=int(m.SIM.token_selection.k1))
+                n2_w=self._p(mi + "norm2.weight"), n2_b=self._p(mi + "norm2.bias"), topk=int(m.SIM.token_selection.k1),
+                dtype=self.dt)
             self.sim_g = fill(
                 _lib.SigSimGrads, w_q=g_in[:d], w_kv=g_in[d:], w_o=self._g(mi + "cross_attn.out_proj.weight"),
                 w_f1=self._g(mi + "ffn.0.weight"), w_f2=self._g(mi + "ffn.2.weight"), b_q=gb_in[:d], b_kv=gb_in[d:],
@@ -273,10 +308,10 @@ class HipPath:
             self.das_param_names = [n for n in fl.names if n.startswith("AlignM.DAS_")]
 
     def _pack(self, cast=True):
-        """f32 -> bf16 for every parameter in one kernel, then the transposed copies."""
+        """f32 -> 16-bit operand type for every parameter in one kernel, then the transposed copies."""
         fl, st = self.flat, _stream()
         if cast:
-            _lib.call("sig_cast_bf16", fl.data.data_ptr(), fl.bf16.data_ptr(), fl.total, st)
+            _lib.call("sig_cast_bf16", fl.data.data_ptr(), fl.op16.data_ptr(), fl.total, self.dt, st)
         if self._tt is None:   # descriptor table of every transposed copy (pointers are stable: flat buffers persist)
             rows = []
             for name, t in self._transposed.items():
@@ -294,15 +329,16 @@ class HipPath:
             self._tt = (torch.tensor(rows, dtype=torch.int64, device=fl.device),
                         torch.tensor(starts, dtype=torch.int32, device=fl.device), len(rows), tot)
         table, starts, n, tot = self._tt
-        _lib.call("sig_transpose_cast_multi", table.data_ptr(), starts.data_ptr(), n, tot, st)
+        _lib.call("sig_transpose_cast_multi", table.data_ptr(), starts.data_ptr(), n, tot, self.dt, st)
 
     # ------------------------------------------------------------------ backbone
     def _alloc_vit(self, S, B, train):
         dev, D, Fd, O, L, H = self.flat.device, self.D, self.F, self.out_dim, self.L, self.H
+        BF = self.operand_dtype
         M, Mt, K = S * L, S * (L - 1), 3 * self.patch * self.patch
         w = _Ws(dev)
         ws = {"S": S, "B": B, "M": M, "train": train}
-        ws["dims"] = _lib.SigVitDims(S, B, L, D, H, Fd, O)
+        ws["dims"] = _lib.SigVitDims(S, B, L, D, H, Fd, O, self.dt)
         ws["img"] = torch.empty(S, 3, *self.img_hw, dtype=F32, device=dev)
         ws["patches"], ws["tok"] = w.z(Mt, K, BF), w.z(Mt, D)
         ws["pre_ln"] = w.z(M, D) if train else None
@@ -337,8 +373,11 @@ class HipPath:
         return ws
 
     def _get_ws(self, pool, key, make):
+        """-> workspace; wrap it in a _WsLease and release() that when done."""
         free = pool.setdefault(key, [])
-        return free.pop() if free else make()
+        ws = free.pop() if free else make()
+        ws["_free"] = free
+        return ws
 
     def vit_forward(self, imgs: List[torch.Tensor], cam: Optional[torch.Tensor], train: bool):
         B = imgs[0].shape[0]
@@ -378,12 +417,10 @@ class HipPath:
 
     on_block_grads_ready = None  # hook for the data-parallel reducer (signal_amd/parallel)
 
-    def release_vit(self, ws):
-        self._vit_ws[(ws["S"], ws["B"], ws["train"])].append(ws)
-
     # ------------------------------------------------------------------ SIM
     def _alloc_sim(self, B, train):
         dev, L = self.flat.device, self.L
+        BF = self.operand_dtype
         Lp, d = L - 1, 512
         Mq, Mk = 3 * B, 3 * B * Lp
         w = _Ws(dev)
@@ -416,9 +453,6 @@ class HipPath:
         _lib.call("sig_sim_bwd", ws["dout"].data_ptr(), B, self.L, ref(self.sim_p), ref(ws["acts"]), ref(self.sim_g),
                   ref(ws["scratch"]), dtokens.data_ptr(), _stream())
 
-    def release_sim(self, ws):
-        self._sim_ws[(ws["B"], ws["train"])].append(ws)
-
 
     # ------------------------------------------------------------------ GAM / LAM
     def gam_forward(self, tokens, B):
@@ -440,6 +474,8 @@ class HipPath:
         h, wd_ = self.model.h, self.model.w
         P, R = (h // 4) * (wd_ // 4), B * (self.L - 1)
 
+        BF = self.operand_dtype
+
         def make():
             w = _Ws(self.flat.device)
             Rp = pad_rows(R)
@@ -451,11 +487,11 @@ class HipPath:
                 ws["s"], ws["scratch"] = s, fill(_lib.SigLamScratch, **s)
             return ws
         ws = self._get_ws(self._lam_ws, (B, train), make)
-        _lib.call("sig_lam_fwd", tokens.data_ptr(), B, self.L, h, wd_, C_ptr(self.das_p), ref(ws["acts"]), _stream())
+        _lib.call("sig_lam_fwd", tokens.data_ptr(), B, self.L, h, wd_, self.dt, C_ptr(self.das_p), ref(ws["acts"]), _stream())
         return ws
 
     def lam_backward(self, ws, tokens, dloss, dtokens):
-        _lib.call("sig_lam_bwd", tokens.data_ptr(), ws["B"], self.L, self.model.h, self.model.w, C_ptr(self.das_p),
+        _lib.call("sig_lam_bwd", tokens.data_ptr(), ws["B"], self.L, self.model.h, self.model.w, self.dt, C_ptr(self.das_p),
                   C_ptr(self.das_g), ref(ws["acts"]), ref(ws["scratch"]), dloss.data_ptr(), dtokens.data_ptr(), _stream())
 
 
@@ -476,14 +512,12 @@ class BackboneFn(torch.autograd.Function):
         imgs, params = args[:n_img], args[n_img:]
         train = hip.grad_mode and any(ctx.needs_input_grad)   # see HipPath.grad_mode
         ws = hip.vit_forward(list(imgs), cam, train)
-        ctx.hip, ctx.ws, ctx.n_img, ctx.train = hip, ws, n_img, train
+        ctx.hip, ctx.ws, ctx.n_img, ctx.train, ctx.lease = hip, ws, n_img, train, _WsLease(ws)
         M = ws["M"]
-        tokens = ws["tokens"][:M].view(ws["S"], hip.L, hip.out_dim)
+        out = ws["tokens"][:M].view(ws["S"], hip.L, hip.out_dim).clone()
         if not train:
-            out = tokens.clone()
-            hip.release_vit(ws)
-            return out
-        return tokens.clone()
+            ctx.lease.release()
+        return out
 
     @staticmethod
     def backward(ctx, dtokens):
@@ -495,7 +529,7 @@ class BackboneFn(torch.autograd.Function):
             hip.zero_grads_of("clip_vision_encoder.")
             hip.vit_backward(ws, dtokens.contiguous())
             grads = hip.grads_of("clip_vision_encoder.", hip.vit_param_names)
-        hip.release_vit(ws)
+        ctx.lease.release()
         return (None, None, None) + (None,) * ctx.n_img + grads
 
 
@@ -507,12 +541,12 @@ class SimFn(torch.autograd.Function):
         train = hip.grad_mode and any(ctx.needs_input_grad)
         tok = tokens.contiguous()   # read row-wise only, so it needs no row padding
         ws = hip.sim_forward(tok, B, train)
-        ctx.hip, ctx.ws, ctx.B, ctx.shape = hip, ws, B, tokens.shape
+        ctx.hip, ctx.ws, ctx.B, ctx.shape, ctx.lease = hip, ws, B, tokens.shape, _WsLease(ws)
         out = ws["t"]["out"][:3 * B].reshape(B, 3 * 512).clone()
         mask = ws["t"]["mask_f"].view(3, B, hip.L - 1).clone()
         ctx.mark_non_differentiable(mask)
         if not train:
-            hip.release_sim(ws)
+            ctx.lease.release()
         return out, mask
 
     @staticmethod
@@ -526,7 +560,7 @@ class SimFn(torch.autograd.Function):
             hip.zero_grads_of("SIM.modal_interactive.")
             hip.sim_backward(ws, dout.contiguous(), dtokens)
             grads = hip.grads_of("SIM.modal_interactive.", hip.sim_param_names)
-        hip.release_sim(ws)
+        ctx.lease.release()
         return (None, None, dtokens) + grads
 
 
@@ -537,10 +571,10 @@ class GamFn(torch.autograd.Function):
     def forward(ctx, hip: HipPath, B, tokens, contra_temp):
         tok = tokens.contiguous()
         ws = hip.gam_forward(tok, B)
-        ctx.hip, ctx.ws, ctx.shape = hip, ws, tokens.shape
+        ctx.hip, ctx.ws, ctx.shape, ctx.lease = hip, ws, tokens.shape, _WsLease(ws)
         out = ws["t"]["loss"][0].clone()
         if not (hip.grad_mode and any(ctx.needs_input_grad)):   # no backward will come: hand the workspace back now
-            hip._gam_ws[(ws["B"],)].append(ws)
+            ctx.lease.release()
         return out
 
     @staticmethod
@@ -554,7 +588,7 @@ class GamFn(torch.autograd.Function):
             hip._g("AlignM.contra_temp").zero_()
             hip.gam_backward(ws, dloss.contiguous().reshape(1), dtokens)
             dtemp = hip._g("AlignM.contra_temp").clone()
-        hip._gam_ws[(ws["B"],)].append(ws)
+        ctx.lease.release()
         return None, None, dtokens, dtemp
 
 
@@ -566,10 +600,10 @@ class LamFn(torch.autograd.Function):
         train = hip.grad_mode and any(ctx.needs_input_grad)
         tok = tokens.contiguous()
         ws = hip.lam_forward(tok, B, train)
-        ctx.hip, ctx.ws, ctx.tok = hip, ws, tok
+        ctx.hip, ctx.ws, ctx.tok, ctx.lease = hip, ws, tok, _WsLease(ws)
         out = ws["t"]["loss"][0].clone()
         if not train:
-            hip._lam_ws[(B, train)].append(ws)
+            ctx.lease.release()
         return out
 
     @staticmethod
@@ -583,5 +617,5 @@ class LamFn(torch.autograd.Function):
             hip.zero_grads_of("AlignM.DAS_")
             hip.lam_backward(ws, ctx.tok, dloss.contiguous().reshape(1), dtokens)
             grads = hip.grads_of("AlignM.DAS_", hip.das_param_names)
-        hip._lam_ws[(ws["B"], ws["train"])].append(ws)
+        ctx.lease.release()
         return (None, None, dtokens) + grads

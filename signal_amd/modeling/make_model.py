@@ -101,7 +101,7 @@ class Signal(nn.Module):
         return float(total)
 
     # ------------------------------------------------------------------
-    def _encode(self, x, cam_label):
+    def _encode(self, x, cam_label, training=True):
         imgs = [x["RGB"], x["NI"], x["TI"]]
         dev = imgs[0].device
         self.hip.prepare(dev)
@@ -118,14 +118,15 @@ class Signal(nn.Module):
                 raise ValueError(f"cam_label has {cam.numel()} entries for a batch of {B}")
         hip = self.hip
         vit_params = [hip.flat.byname[n] for n in hip.vit_param_names]
-        hip.grad_mode = torch.is_grad_enabled()
+        # training=False never differentiates: take the (small, ping-pong) inference workspace even under grad mode
+        hip.grad_mode = torch.is_grad_enabled() and bool(training)
         tokens = BackboneFn.apply(hip, cam, 3, *[im.contiguous().float() for im in imgs], *vit_params)
         tok4 = tokens.view(3, B, hip.L, hip.out_dim)
         return tokens, tok4[:, :, 1:], tok4[:, :, 0]
 
-    def _sim(self, tokens, B):
+    def _sim(self, tokens, B, training=True):
         hip = self.hip
-        hip.grad_mode = torch.is_grad_enabled()
+        hip.grad_mode = torch.is_grad_enabled() and bool(training)
         out, mask = SimFn.apply(hip, B, tokens, *[hip.flat.byname[n] for n in hip.sim_param_names])
         m = mask.unsqueeze(-1)
         self.SIM.token_selection.last_masks = {"RGB": m[0], "NI": m[1], "TI": m[2]}
@@ -142,10 +143,10 @@ class Signal(nn.Module):
         if not training and "cam_label" in x:
             cam_label = x["cam_label"]
         B = x["RGB"].shape[0]
-        tokens, patches, cls = self._encode(x, cam_label)
+        tokens, patches, cls = self._encode(x, cam_label, training)
         RGB_global, NI_global, TI_global = cls[0], cls[1], cls[2]
 
-        vars_total = self._sim(tokens, B) if self.use_A else None
+        vars_total = self._sim(tokens, B, training) if self.use_A else None
         loss_area = patch_loss = None
         if self.use_B and training:
             # the reference also evaluates AlignM at inference and discards it (make_model.py:277-281);

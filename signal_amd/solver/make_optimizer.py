@@ -42,16 +42,49 @@ class FusedAdam(torch.optim.Optimizer):
         self.m = torch.zeros_like(fl.data)
         self.v = torch.zeros_like(fl.data)
         self.t = 0
-        ends, self._seg_group = [], []
-        by_name = {n: i for i, n in enumerate(self._names)}
+        ends = []
+        self._by_name = {n: i for i, n in enumerate(self._names)}
         for n in fl.names:
             ends.append(fl.offsets[n] + (fl.byname[n].numel() + 63) // 64 * 64)
-            self._seg_group.append(by_name.get(n))     # None: frozen / grad-less -> lr 0
         self.seg_end = torch.tensor(ends, dtype=torch.int32, device=fl.device)
         self.seg_lr = torch.zeros(len(ends), dtype=torch.float32, device=fl.device)
         self.seg_wd = torch.zeros(len(ends), dtype=torch.float32, device=fl.device)
         self._host = None
         self.grad_scale = 1.0
+        self.set_inactive(gradless)
+
+    def set_inactive(self, pred):
+        """Parameters with no gradient path (pred(name) true) or frozen ones are left untouched -- lr 0 and weight decay 0
+        for their segment -- which is what torch.optim does with .grad = None."""
+        fl = self.hip.flat
+        self._seg_group = [None if pred(n) else self._by_name.get(n) for n in fl.names]
+        self._host = None
+
+    # ---- adopting a torch.optim.Adam built by the reference's make_optimizer on a CPU model (train.py:85) -------------
+    @staticmethod
+    def can_adopt(opt) -> bool:
+        if type(opt) is not torch.optim.Adam or len(opt.state) != 0:
+            return False
+        d = opt.defaults
+        plain = not (d.get("amsgrad") or d.get("maximize") or d.get("capturable") or d.get("differentiable"))
+        return plain and all(len(g["params"]) == 1 and g["params"][0].is_cuda for g in opt.param_groups)
+
+    @classmethod
+    def adopt(cls, opt, model):
+        """Same param_groups LIST and dicts as `opt` (a scheduler built on `opt` keeps steering the learning rates),
+        update applied by the fused kernel."""
+        hip = model.hip
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        named = []
+        for g in opt.param_groups:
+            n = name_of.get(id(g["params"][0]))
+            if n is None:
+                raise ValueError("FusedAdam.adopt: the optimizer holds a parameter that is not the model's")
+            named.append((n, g))
+        g0 = opt.param_groups[0]
+        self = cls(named, hip, betas=tuple(g0.get("betas", opt.defaults["betas"])), eps=float(g0.get("eps", opt.defaults["eps"])))
+        self.param_groups = opt.param_groups
+        return self
 
     def _sync_table(self):
         host = tuple((0.0, 0.0) if gi is None else (float(self.param_groups[gi]["lr"]), float(self.param_groups[gi]["weight_decay"]))
@@ -62,15 +95,18 @@ class FusedAdam(torch.optim.Optimizer):
             self.seg_wd.copy_(torch.tensor([h[1] for h in host], dtype=torch.float32), non_blocking=True)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, scaler=None):
+        """scaler (engine.trainer.DeviceLossScaler) = fp16 mode: the gradient is divided by the device-resident loss scale,
+        the whole update is skipped when scaler.check() found a non-finite gradient, and the bias-correction step count is
+        the device's count of APPLIED steps (GradScaler.step semantics)."""
         fl = self.hip.flat
         self._sync_table()
         self.t += 1
         b1, b2 = self.defaults["betas"]
         _lib.call("sig_adam_step", fl.data.data_ptr(), fl.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                  fl.bf16.data_ptr(), self.seg_end.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(),
+                  fl.op16.data_ptr(), self.hip.dt, self.seg_end.data_ptr(), self.seg_lr.data_ptr(), self.seg_wd.data_ptr(),
                   len(self._seg_group), float(b1), float(b2), float(self.defaults["eps"]), self.t, float(self.grad_scale),
-                  fl.total, torch.cuda.current_stream().cuda_stream)
+                  None if scaler is None else scaler.state.data_ptr(), fl.total, torch.cuda.current_stream().cuda_stream)
         self.hip.after_fused_step()
 
     def zero_grad(self, set_to_none: bool = False):
@@ -89,9 +125,8 @@ def make_optimizer(cfg, model, center_criterion=None):
     if name == "Adam" and next(model.parameters()).is_cuda:
         hip = model.hip
         hip.prepare(next(model.parameters()).device)
-        hip.enable_direct_grads()
-        live = [(k, g) for k, g in named if not gradless(k)]
-        return FusedAdam(live, hip), None
+        hip.enable_direct_grads(skip=gradless)
+        return FusedAdam(named, hip), None
     groups = [g for _, g in named]
     if name == "SGD":
         return torch.optim.SGD(groups, momentum=cfg.SOLVER.MOMENTUM), None

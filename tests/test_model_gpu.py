@@ -21,9 +21,10 @@ def rel_err(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def make_cfg(ocfg: O.RefConfig):
+def make_cfg(ocfg: O.RefConfig, dtype="bf16"):
     from signal_amd.config import get_cfg_defaults
     c = get_cfg_defaults()
+    c.MODEL.OPERAND_DTYPE = dtype
     c.MODEL.TRANSFORMER_TYPE = "ViT-B-16"
     c.MODEL.SIE_COE = ocfg.sie_coe
     c.MODEL.SIE_CAMERA = ocfg.sie_camera
@@ -38,9 +39,9 @@ def make_cfg(ocfg: O.RefConfig):
     return c
 
 
-def build(ocfg, sd, dev):
+def build(ocfg, sd, dev, dtype="bf16"):
     from signal_amd.modeling import make_frame
-    model = make_frame(make_cfg(ocfg), ocfg.num_classes, ocfg.camera_num, 0)
+    model = make_frame(make_cfg(ocfg, dtype), ocfg.num_classes, ocfg.camera_num, 0)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     assert all("num_batches_tracked" in k for k in missing), missing
