@@ -1,1 +1,1 @@
-from .pipeline import DevicePrefetcher, PKSampler, SyntheticTriplets, shard_for_rank  # noqa: F401
+from .pipeline import DevicePrefetcher, PKSampler, SyntheticTriplets, epoch_seed, shard_for_rank  # noqa: F401

@@ -7,7 +7,8 @@ Reference behaviour mirrored here:
     [mb*r + mb*W*i, mb*r + mb*W*i + mb) of the global list (:165-175); BatchSampler(drop_last=True)
     (make_dataloader.py:215-218).
   * the shared seed: the reference all-gathers a pickled int over a gloo side group every epoch (:105-115); here the
-    seed is a pure function of (base_seed, epoch), so no collective is needed at all.
+    seed is a pure function of (base_seed, epoch), so no collective is needed at all.  Given the same seed the index lists
+    are bit-identical to the reference's (tests/golden/g9_sampler.npz).
   * host -> device copies (engine/processor.py:155-162) are blocking .to(device) calls there; here batches are staged
     in pinned memory and copied on a side HIP stream one step ahead (75.5 MB per B=64 step of f32 triplets)."""
 from __future__ import annotations
@@ -33,9 +34,20 @@ def shard_for_rank(indices: Sequence[int], mini_batch: int, rank: int, world: in
     return out
 
 
+def epoch_seed(base_seed: int, epoch: int) -> int:
+    """The per-epoch seed every rank uses.  The reference draws np.random.randint(2**31) on each rank and all-gathers rank
+    0's value over a gloo side group (sampler_ddp.py:105-115); a pure function of (base seed, epoch) gives every rank the
+    same value with no collective."""
+    return int(np.random.RandomState([int(base_seed) & 0xFFFFFFFF, int(epoch) & 0xFFFFFFFF]).randint(2 ** 31))
+
+
 class PKSampler:
     """P identities x K instances per mini-batch, sharded over ranks; iterate to get this rank's sample indices
-    (feed to torch BatchSampler(drop_last=True) or use batches())."""
+    (feed to torch BatchSampler(drop_last=True) or use batches()).
+
+    For a given shared seed the index lists are the reference's (RandomIdentitySampler_DDP.sample_list and
+    __fetch_current_node_idxs, sampler_ddp.py:154-199: same legacy-MT19937 stream, same call order -- pinned by
+    tests/golden/g9_sampler.npz, which records that file's own output for world sizes 1, 2 and 8)."""
 
     def __init__(self, pids: Sequence[int], batch_size: int, num_instances: int, rank: int = 0, world: int = 1,
                  seed: int = 1234):
@@ -49,22 +61,25 @@ class PKSampler:
             self.index_dic[int(pid)].append(i)
         self.pids = list(self.index_dic)
         self.epoch = 0
+        self.shared_seed = None
 
-    def set_epoch(self, epoch: int):
-        self.epoch = epoch
+    def set_epoch(self, epoch: int, shared_seed: int = None):
+        """shared_seed: use this value instead of epoch_seed(seed, epoch) (e.g. one exchanged the reference's way)."""
+        self.epoch, self.shared_seed = epoch, shared_seed
 
     def global_list(self) -> List[int]:
-        rng = np.random.default_rng([self.seed, self.epoch])       # same on every rank: no seed exchange
+        seed = self.shared_seed if self.shared_seed is not None else epoch_seed(self.seed, self.epoch)
+        rs = np.random.RandomState(seed)                   # = np.random.seed(seed) + the module-level functions
         avail = copy.copy(self.pids)
         pools: Dict[int, List[int]] = {}
         out: List[int] = []
         while len(avail) >= self.p:
-            for pid in rng.choice(avail, self.p, replace=False).tolist():
+            for pid in rs.choice(avail, self.p, replace=False).tolist():
                 if pid not in pools:
                     idxs = list(self.index_dic[pid])
                     if len(idxs) < self.k:
-                        idxs = rng.choice(idxs, size=self.k, replace=True).tolist()
-                    rng.shuffle(idxs)
+                        idxs = rs.choice(idxs, size=self.k, replace=True).tolist()
+                    rs.shuffle(idxs)
                     pools[pid] = idxs
                 pool = pools[pid]
                 out.extend(pool[: self.k])
@@ -75,6 +90,9 @@ class PKSampler:
 
     def __iter__(self) -> Iterator[int]:
         return iter(shard_for_rank(self.global_list(), self.mini_batch, self.rank, self.world))
+
+    def __len__(self) -> int:
+        return len(shard_for_rank(self.global_list(), self.mini_batch, self.rank, self.world))
 
     def batches(self) -> Iterator[List[int]]:
         mine = list(self)
@@ -93,6 +111,10 @@ class SyntheticTriplets:
 
     def __len__(self):
         return self.steps
+
+    @property
+    def batch_size(self):            # torch DataLoader's attribute; engine/processor.py:293-302 reads it for the speed log
+        return self.batch
 
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed)

@@ -4,8 +4,8 @@
              loss_fn, num_query, local_rank, stage)
     do_inference(cfg, model, val_loader, num_query, logger, sge, local_rank)
 
-so the reference's train.py / test.py call them unchanged.  Differences, all on the host side: bf16 needs no
-GradScaler; gradients are reduced by signal_amd.parallel.GradReducer instead of DistributedDataParallel; rank 0
+so the reference's train.py / test.py call them unchanged.  Differences, all on the host side: the GradScaler of
+processor.py:119,259-261 lives on the device (fp16 operand mode; bf16 needs none); gradients are reduced by signal_amd.parallel.GradReducer instead of DistributedDataParallel; rank 0
 evaluates/saves and the other ranks wait at a barrier (the reference lets them run ahead into the next
 all-reduce); checkpoints never carry a 'module.' prefix."""
 from __future__ import annotations
@@ -49,8 +49,10 @@ def do_train(cfg, model, center_criterion, train_loader, val_loader, optimizer, 
     model.to(device)
     world = dist.get_world_size() if (cfg.MODEL.DIST_TRAIN and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
-    engine = TrainStep(cfg, model, num_classes=model.num_classes, world_size=world, loss_fn=loss_fn, optimizer=optimizer)
-    engine.stage = stage
+    # `optimizer` normally is the torch.optim.Adam that train.py built on the CPU model (train.py:85): TrainStep adopts its
+    # param_groups (the scheduler keeps steering them) and applies the update with the fused kernel
+    engine = TrainStep(cfg, model, num_classes=model.num_classes, world_size=world, loss_fn=loss_fn, optimizer=optimizer,
+                       stage=stage)
     loss_meter, acc_meter = AverageMeter(), AverageMeter()
     evaluator = R1_mAP_eval(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM)
     best = {"mAP": 0.0, "Rank-1": 0.0, "Rank-5": 0.0, "Rank-10": 0.0}

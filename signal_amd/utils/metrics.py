@@ -1,23 +1,77 @@
 """Retrieval metrics of the evaluation loop (utils/metrics.py:111-170,222-300,494-500 of the reference):
 market1501-style CMC / mAP where, per query, gallery images of the same identity AND camera are discarded.
-Vectorised NumPy restatement; the t-SNE/KDE plotting side effects of the reference's compute() (hard-coded
-home-directory paths, utils/metrics.py:289-297) are intentionally absent."""
+
+The feature work runs on the GPU: features stay in HBM as they arrive, L2 normalisation is one torch op, and the
+distance matrix |q|^2 + |g|^2 - 2 q.g^T -- the reference's `addmm_` (utils/metrics.py:494-500) -- is formed by the hand-
+written MFMA GEMM (sig_gemm_nt) with each operand split into three bf16 terms (x = x0 + x1 + x2, six partial products
+accumulated in f32 through the residual epilogue), which reproduces an f32 product to ~1e-7: rankings match an f32
+evaluation.  Ranking statistics (argsort on the device, CMC / AP per query in NumPy) are host post-processing exactly as
+in the reference.  The t-SNE / KDE plotting side effects of the reference's compute() (hard-coded home-directory paths,
+utils/metrics.py:289-297) are intentionally absent.
+
+Parity status: the reference's utils/metrics.py cannot be imported in the build container (seaborn and
+scipy.integrate.simps are missing), so this evaluator is pinned by hand-derived cases (tests/test_metrics_cpu.py) and by an
+independent float64 evaluation (tests/test_eval_gpu.py), not by reference outputs: "parity unpinned"."""
 from __future__ import annotations
 
 import numpy as np
 import torch
 
-
-def euclidean_distance(qf: torch.Tensor, gf: torch.Tensor) -> np.ndarray:
-    """squared Euclidean distance matrix (utils/metrics.py:494-500)"""
-    d = qf.pow(2).sum(1, keepdim=True) + gf.pow(2).sum(1, keepdim=True).t() - 2.0 * qf @ gf.t()
-    return d.cpu().numpy()
+from .. import _lib, ops
 
 
-def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50):
+def _split3(x: torch.Tensor, rows: int, cols: int):
+    """f32 [n, d] -> three bf16 [rows, cols] zero-padded terms whose sum is x to ~2^-24."""
+    parts, r = [], x.float()
+    for _ in range(3):
+        p = r.to(torch.bfloat16)
+        r = r - p.float()
+        buf = torch.zeros(rows, cols, dtype=torch.bfloat16, device=x.device)
+        buf[: x.shape[0], : x.shape[1]] = p
+        parts.append(buf)
+    return parts
+
+
+def gram_f32(qf: torch.Tensor, gf: torch.Tensor) -> torch.Tensor:
+    """qf [m, d] @ gf[n, d]^T in (near-)f32 accuracy on the MFMA GEMM; device tensors only."""
+    if not (qf.is_cuda and gf.is_cuda):
+        raise _lib.SignalHipError("euclidean_distance: features must be device tensors (signal_amd has no CPU path)")
+    m, d = qf.shape
+    n = gf.shape[0]
+    dp, np_ = (d + 63) // 64 * 64, (n + 127) // 128 * 128
+    q3, g3 = _split3(qf, ops.pad_rows(m), dp), _split3(gf, np_, dp)
+    out = torch.zeros(ops.pad_rows(m), np_, dtype=torch.float32, device=qf.device)
+    first = True
+    # smallest terms first so they are not absorbed: (i, j) with i + j descending, dropping i + j > 2 (below f32 resolution)
+    for i, j in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
+        if first:
+            ops.gemm_nt(q3[i], g3[j], m, ops.F32, out)
+            first = False
+        else:
+            ops.gemm_nt(q3[i], g3[j], m, ops.RES_F32, out, res=out)
+    return out[:m, :n]
+
+
+def euclidean_distance(qf: torch.Tensor, gf: torch.Tensor) -> torch.Tensor:
+    """squared Euclidean distance matrix (utils/metrics.py:494-500), f32 on the device"""
+    qf, gf = qf.float(), gf.float()
+    return qf.pow(2).sum(1, keepdim=True) + gf.pow(2).sum(1, keepdim=True).t() - 2.0 * gram_f32(qf, gf)
+
+
+def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, order=None):
+    """CMC curve and mAP (utils/metrics.py:111-170).  `order` = precomputed argsort of distmat rows (device-side sort).
+
+    One deliberate difference: when fewer than max_rank gallery items survive a query's same-id-same-camera filter its CMC
+    row is shorter than the others; the reference then builds a ragged `np.asarray(all_cmc)` (metrics.py:151,167) and fails.
+    Here a short row is extended with its last value (a match once found stays found), which is what the curve means."""
+    distmat = np.asarray(distmat)
+    q_pids, g_pids, q_camids, g_camids = (np.asarray(a) for a in (q_pids, g_pids, q_camids, g_camids))
     num_q, num_g = distmat.shape
-    max_rank = min(max_rank, num_g)
-    order = np.argsort(distmat, axis=1)
+    if num_g < max_rank:
+        max_rank = num_g
+        print("Note: number of gallery samples is quite small, got {}".format(num_g))
+    if order is None:
+        order = np.argsort(distmat, axis=1)
     all_cmc, all_ap = [], []
     for q in range(num_q):
         o = order[q]
@@ -39,26 +93,36 @@ def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50):
 
 
 class R1_mAP_eval:
-    def __init__(self, num_query, max_rank=50, feat_norm="yes"):
+    """utils/metrics.py:222-300: reset() / update((feat, pid, camid[, img_paths])) / compute().  `feat_norm` is used by
+    truthiness as in the reference (metrics.py:265: `if self.feat_norm:`), so both 'yes' and 'no' -- the two values of
+    cfg.TEST.FEAT_NORM -- normalise; pass False / '' to skip."""
+
+    def __init__(self, num_query, max_rank=50, feat_norm=True, reranking=False):
+        if reranking:
+            raise NotImplementedError("k-reciprocal re-ranking (utils/reranking.py) is outside the hot path (TEST.RE_RANKING='no')")
         self.num_query, self.max_rank, self.feat_norm = num_query, max_rank, feat_norm
         self.reset()
 
     def reset(self):
-        self.feats, self.pids, self.camids = [], [], []
+        self.feats, self.pids, self.camids, self.img_paths = [], [], [], []
 
     def update(self, output):
         feat, pid, camid = output[0], output[1], output[2]
-        self.feats.append(feat.detach().float().cpu())
+        self.feats.append(feat.detach().float())          # stays where it is (HBM)
         self.pids.extend(np.asarray(pid).tolist())
         self.camids.extend(np.asarray(camid).tolist())
+        if len(output) > 3:
+            self.img_paths.extend(output[3])
 
     def compute(self):
         feats = torch.cat(self.feats, dim=0)
-        if self.feat_norm == "yes":
+        if self.feat_norm:
             feats = torch.nn.functional.normalize(feats, dim=1, p=2)
         qf, gf = feats[: self.num_query], feats[self.num_query:]
         q_pids, g_pids = np.asarray(self.pids[: self.num_query]), np.asarray(self.pids[self.num_query:])
         q_cam, g_cam = np.asarray(self.camids[: self.num_query]), np.asarray(self.camids[self.num_query:])
-        distmat = euclidean_distance(qf, gf)
-        cmc, mAP = eval_func(distmat, q_pids, g_pids, q_cam, g_cam, self.max_rank)
+        dist = euclidean_distance(qf, gf)
+        order = torch.argsort(dist, dim=1, stable=True).cpu().numpy()
+        distmat = dist.cpu().numpy()
+        cmc, mAP = eval_func(distmat, q_pids, g_pids, q_cam, g_cam, self.max_rank, order=order)
         return cmc, mAP, distmat, self.pids, self.camids, qf, gf

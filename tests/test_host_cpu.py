@@ -298,3 +298,33 @@ def test_warmup_multistep_matches_reference(golden, tag, wit):
     np.testing.assert_allclose(np.array(rows), g[f"{tag}_lr"], rtol=1e-12, atol=0)
     with pytest.raises(ValueError):
         WarmupMultiStepLR(opt, [40, 20])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N3: the P x K sampler against G9 (index lists produced by the reference's own data/datasets/sampler_ddp.py,
+# tests/golden/make_golden_sampler.py)
+# ---------------------------------------------------------------------------------------------------------
+def test_pk_sampler_reproduces_the_reference_ddp_sampler(golden):
+    from signal_amd.data import PKSampler, shard_for_rank
+    g = golden("g9_sampler")
+    pids = g["pids"]
+    for ci, (world, bs, k) in enumerate(g["cases"].tolist()):
+        for epoch in range(2):
+            seed, want = int(g[f"c{ci}_e{epoch}_seed"]), g[f"c{ci}_e{epoch}_ranks"]
+            assert want.shape[0] == world
+            glob = None
+            for r in range(world):
+                s = PKSampler(pids, bs, k, rank=r, world=world)
+                s.set_epoch(epoch, shared_seed=seed)
+                got = np.array(list(s), dtype=np.int64)
+                assert got.shape == want[r].shape and (got == want[r]).all(), (ci, epoch, r)
+                assert len(s) == len(got)
+                glob = s.global_list() if glob is None else glob
+                assert s.global_list() == glob                      # every rank walks the same global list
+                assert list(got) == shard_for_rank(glob, bs // world, r, world)
+    # without an injected seed the epoch seed is a pure function of (base seed, epoch): identical on every rank, no collective
+    a, b = PKSampler(pids, 32, 4, rank=0, world=2, seed=99), PKSampler(pids, 32, 4, rank=1, world=2, seed=99)
+    a.set_epoch(3), b.set_epoch(3)
+    assert a.global_list() == b.global_list() and not (set(a) & set(b))
+    a.set_epoch(4)
+    assert a.global_list() != b.global_list()

@@ -1,5 +1,6 @@
 """Per-kernel parity on a real MI355X: each HIP primitive, called through the C ABI, against a plain
-PyTorch fp32 evaluation of the same op on the same (bf16-rounded) inputs."""
+PyTorch fp32 evaluation of the same op on the same (16-bit-rounded) inputs, for both MFMA operand types
+(bf16 and fp16; `T` scales the output-rounding tolerances: 2^-9 vs 2^-12 relative per element)."""
 import math
 
 import pytest
@@ -15,13 +16,18 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["bf16", "fp16"])
+def dt16(request):
+    return torch.bfloat16 if request.param == "bf16" else torch.float16
+
+
+def tol_scale(dt16):
+    return 1.0 if dt16 is torch.bfloat16 else 0.15
+
+
 def _ops():
     from signal_amd import ops
     return ops
-
-
-def bf(t):
-    return t.to(torch.bfloat16)
 
 
 def rel_err(a, b):
@@ -42,8 +48,10 @@ GEMM_SHAPES = [(774, 384, 128), (1000, 768, 3072), (4128, 2304, 768), (129, 128,
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
-def test_gemm_nt_epilogues(dev, m, n, k):
+def test_gemm_nt_epilogues(dev, dt16, m, n, k):
     ops = _ops()
+    T = tol_scale(dt16)
+    bf = lambda t: t.to(dt16)
     g = torch.Generator(device="cpu").manual_seed(m + n + k)
     a = bf(torch.randn(m, k, generator=g)).to(dev)
     # asymmetric operands (cdna guide: a symmetric B hides a transposed C write)
@@ -69,33 +77,33 @@ def test_gemm_nt_epilogues(dev, m, n, k):
     ops.gemm_nt(ap, w, m, ops.BIAS_RES_F32, x, bias=bias, res=x)
     assert rel_err(x[:m], ref + bias + res) < 2e-6
 
-    ob = torch.zeros(ops.pad_rows(m), n, device=dev, dtype=torch.bfloat16)
+    ob = torch.zeros(ops.pad_rows(m), n, device=dev, dtype=dt16)
     ops.gemm_nt(ap, w, m, ops.BF16, ob)
-    assert rel_err(ob[:m].float(), ref) < 3e-3
+    assert rel_err(ob[:m].float(), ref) < 3e-3 * T
     ops.gemm_nt(ap, w, m, ops.BIAS_BF16, ob, bias=bias)
-    assert rel_err(ob[:m].float(), ref + bias) < 3e-3
+    assert rel_err(ob[:m].float(), ref + bias) < 3e-3 * T
 
     u = torch.zeros_like(ob)
     ops.gemm_nt(ap, w, m, ops.BIAS_GELU_BF16, ob, bias=bias, aux=u)
     pre = ref + bias
-    assert rel_err(u[:m].float(), pre) < 3e-3
-    assert rel_err(ob[:m].float(), pre * torch.sigmoid(1.702 * pre)) < 4e-3
+    assert rel_err(u[:m].float(), pre) < 3e-3 * T
+    assert rel_err(ob[:m].float(), pre * torch.sigmoid(1.702 * pre)) < 4e-3 * T
 
     # dgelu: out = acc * QuickGELU'(u)
     uu = bf(torch.randn(m, n, generator=g)).to(dev)
     ops.gemm_nt(ap, w, m, ops.DGELU_BF16, ob, aux=padded(uu, ops))
     s = torch.sigmoid(1.702 * uu.float())
-    assert rel_err(ob[:m].float(), ref * (s * (1 + 1.702 * uu.float() * (1 - s)))) < 4e-3
+    assert rel_err(ob[:m].float(), ref * (s * (1 + 1.702 * uu.float() * (1 - s)))) < 4e-3 * T
     assert not bool(ob[m:].abs().any()), "pad rows must stay untouched"
 
     # erf-GELU pair (SIM's FFN) and the bias-free residual epilogue
     ops.gemm_nt(ap, w, m, ops.BIAS_GELUERF_BF16, ob, bias=bias, aux=u)
-    assert rel_err(u[:m].float(), pre) < 3e-3
-    assert rel_err(ob[:m].float(), torch.nn.functional.gelu(pre)) < 4e-3
+    assert rel_err(u[:m].float(), pre) < 3e-3 * T
+    assert rel_err(ob[:m].float(), torch.nn.functional.gelu(pre)) < 4e-3 * T
     ops.gemm_nt(ap, w, m, ops.DGELUERF_BF16, ob, aux=padded(uu, ops))
     uf = uu.float()
     dg = 0.5 * (1 + torch.erf(uf * 0.7071067811865476)) + uf * torch.exp(-0.5 * uf * uf) * 0.3989422804014327
-    assert rel_err(ob[:m].float(), ref * dg) < 4e-3
+    assert rel_err(ob[:m].float(), ref * dg) < 4e-3 * T
     out.zero_()
     ops.gemm_nt(ap, w, m, ops.RES_F32, out, res=res)
     assert rel_err(out[:m], ref + res) < 2e-6
@@ -104,8 +112,9 @@ def test_gemm_nt_epilogues(dev, m, n, k):
 
 @pytest.mark.parametrize("mr,i,j", [(128, 128, 128), (896, 384, 128), (4160, 768, 256), (24832, 256, 128), (8192, 1536, 768),
                                     (4160, 2304, 768), (64, 1536, 768)])
-def test_gemm_tn(dev, mr, i, j):
+def test_gemm_tn(dev, dt16, mr, i, j):
     ops = _ops()
+    bf = lambda t: t.to(dt16)
     g = torch.Generator(device="cpu").manual_seed(mr + i)
     p = bf(torch.randn(mr, i, generator=g) * 0.1 + torch.linspace(-0.1, 0.2, i)[None]).to(dev)
     q = bf(torch.randn(mr, j, generator=g)).to(dev)
@@ -120,19 +129,21 @@ def test_gemm_tn(dev, mr, i, j):
 
 
 @pytest.mark.parametrize("m,d", [(774, 768), (1000, 512), (37, 128), (5, 1024)])
-def test_layernorm(dev, m, d):
+def test_layernorm(dev, dt16, m, d):
     ops = _ops()
+    T = tol_scale(dt16)
+    bf = lambda t: t.to(dt16)
     g = torch.Generator(device="cpu").manual_seed(m * d)
     x = (torch.randn(m, d, generator=g) * 2 + 0.5).to(dev)
     w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
     b = (0.1 * torch.randn(d, generator=g)).to(dev)
-    yb = torch.zeros(m, d, device=dev, dtype=torch.bfloat16)
+    yb = torch.zeros(m, d, device=dev, dtype=dt16)
     yf = torch.zeros(m, d, device=dev)
     mean, rstd = torch.zeros(m, device=dev), torch.zeros(m, device=dev)
     ops.layernorm_fwd(x, w, b, m, y_bf16=yb, y_f32=yf, mean=mean, rstd=rstd)
     ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-5)
     assert rel_err(yf, ref) < 1e-6
-    assert rel_err(yb.float(), ref) < 3e-3
+    assert rel_err(yb.float(), ref) < 3e-3 * T
     assert rel_err(mean, x.mean(1)) < 1e-5
 
     # backward (f32 and bf16 dy), with residual gradient and parameter grads
@@ -141,13 +152,13 @@ def test_layernorm(dev, m, d):
     xr = x.clone().requires_grad_(True)
     wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5).backward(dy)
-    for dyt, tol in ((dy, 2e-6), (bf(dy), 4e-3)):
+    for dyt, tol in ((dy, 2e-6), (bf(dy), 4e-3 * T)):
         dxf = torch.zeros(m, d, device=dev)
-        dxb = torch.zeros(m, d, device=dev, dtype=torch.bfloat16)
+        dxb = torch.zeros(m, d, device=dev, dtype=dt16)
         dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
         ops.layernorm_bwd(dyt, x, w, mean, rstd, m, dres=dres, dx_f32=dxf, dx_bf16=dxb, dgamma=dg, dbeta=db)
         assert rel_err(dxf, xr.grad + dres) < tol
-        assert rel_err(dxb.float(), xr.grad + dres) < 4e-3
+        assert rel_err(dxb.float(), xr.grad + dres) < 4e-3 * T
         assert rel_err(dg, wr.grad) < max(tol, 2e-5)
         assert rel_err(db, br.grad) < max(tol, 2e-5)
 
@@ -160,18 +171,20 @@ def _attn_ref(qkv, s, l, h):
 
 
 @pytest.mark.parametrize("s,l,h", [(3, 129, 2), (6, 129, 12), (2, 17, 1), (2, 128, 2), (1, 144, 3)])
-def test_attention_fwd_bwd(dev, s, l, h):
+def test_attention_fwd_bwd(dev, dt16, s, l, h):
     ops = _ops()
+    T = tol_scale(dt16)
+    bf = lambda t: t.to(dt16)
     g = torch.Generator(device="cpu").manual_seed(s * l + h)
     d = h * 64
     qkv = bf(torch.randn(s * l, 3 * d, generator=g) * 1.5).to(dev)
     qkv_p = padded(qkv, ops)
-    out = torch.zeros(ops.pad_rows(s * l), d, device=dev, dtype=torch.bfloat16)
+    out = torch.zeros(ops.pad_rows(s * l), d, device=dev, dtype=dt16)
     lse = torch.zeros(s, h, l, device=dev)
     ops.attn_fwd(qkv_p, out, lse, s, l, h)
     qr = qkv.float().requires_grad_(True)
     ref, ref_lse = _attn_ref(qr, s, l, h)
-    assert rel_err(out[: s * l].float(), ref) < 6e-3
+    assert rel_err(out[: s * l].float(), ref) < 6e-3 * T
     assert rel_err(lse, ref_lse) < 1e-5
     assert not bool(out[s * l:].float().abs().any()), "pad rows must stay untouched"
 
@@ -181,23 +194,24 @@ def test_attention_fwd_bwd(dev, s, l, h):
     ops.attn_bwd(qkv_p, out, padded(dout, ops), lse, dqkv, s, l, h)
     gq, gk, gv = (qr.grad[:, i * d:(i + 1) * d] for i in range(3))
     hq, hk, hv = (dqkv[: s * l, i * d:(i + 1) * d].float() for i in range(3))
-    assert rel_err(hv, gv) < 1e-2
-    assert rel_err(hk, gk) < 1.5e-2
-    assert rel_err(hq, gq) < 1.5e-2
+    assert rel_err(hv, gv) < 1e-2 * T
+    assert rel_err(hk, gk) < 1.5e-2 * T
+    assert rel_err(hq, gq) < 1.5e-2 * T
 
 
-def test_cast_transpose_colsum(dev):
+def test_cast_transpose_colsum(dev, dt16):
     ops = _ops()
+    bf = lambda t: t.to(dt16)
     g = torch.Generator(device="cpu").manual_seed(7)
     w = torch.randn(3072, 768, generator=g).to(dev)
-    d1 = torch.empty(3072, 768, device=dev, dtype=torch.bfloat16)
-    d2 = torch.empty(768, 3072, device=dev, dtype=torch.bfloat16)
+    d1 = torch.empty(3072, 768, device=dev, dtype=dt16)
+    d2 = torch.empty(768, 3072, device=dev, dtype=dt16)
     ops.cast_bf16(w, d1)
     ops.transpose_cast_bf16(w, d2)
     assert torch.equal(d1, bf(w))
     assert torch.equal(d2, bf(w).t().contiguous())
     odd = torch.randn(1003, generator=g).to(dev)
-    o = torch.empty(1003, device=dev, dtype=torch.bfloat16)
+    o = torch.empty(1003, device=dev, dtype=dt16)
     ops.cast_bf16(odd, o)
     assert torch.equal(o, bf(odd))
     for m, n in ((774, 768), (1000, 2304), (130, 512)):
@@ -209,9 +223,10 @@ def test_cast_transpose_colsum(dev):
 
 
 @pytest.mark.parametrize("hw", [(256, 128), (128, 256)])
-def test_embed_front_end(dev, hw):
+def test_embed_front_end(dev, dt16, hw):
     """im2col + conv1-as-GEMM + token assembly + ln_pre against the oracle's vit_embed."""
     ops = _ops()
+    bf = lambda t: t.to(dt16)
     from oracle import signal_ref as O
     cfg = O.RefConfig(size_train=hw, layers=1, use_a=False, use_b=False)
     sd = O.init_state_dict(cfg, seed=5)
@@ -221,7 +236,7 @@ def test_embed_front_end(dev, hw):
     D, L, Lp = cfg.width, cfg.tokens, cfg.tokens - 1
     S = 3 * B
     imgs = torch.cat([img[m] for m in O.MODALITIES]).to(dev)
-    patches = torch.zeros(ops.pad_rows(S * Lp), 3 * 256, device=dev, dtype=torch.bfloat16)
+    patches = torch.zeros(ops.pad_rows(S * Lp), 3 * 256, device=dev, dtype=dt16)
     ops.im2col(imgs, patches, 16)
     wconv = bf(sd[base + "conv1.weight"].reshape(D, -1)).to(dev)
     tok = torch.zeros(ops.pad_rows(S * Lp), D, device=dev)
@@ -235,14 +250,14 @@ def test_embed_front_end(dev, hw):
                        x, pre, mean, rstd, S, B, L, D)
     ref = torch.cat([O.vit_embed(sd, cfg, img[m], cfg.sie_coe * sd["clip_vision_encoder.cv_embed"][cam])
                      for m in O.MODALITIES]).reshape(S * L, D)
-    assert rel_err(x.cpu(), ref) < 5e-3          # bf16 conv operands
+    assert rel_err(x.cpu(), ref) < 5e-3 * tol_scale(dt16)          # 16-bit conv operands
     # CLS rows involve no bf16 at all
     assert rel_err(x.reshape(S, L, D)[:, 0].cpu(), ref.reshape(S, L, D)[:, 0]) < 1e-6
 
     # backward of the assembly
     dpre = torch.randn(S * L, D, device=dev)
     dtok = torch.zeros(S * Lp, D, device=dev)
-    dtokb = torch.zeros(S * Lp, D, device=dev, dtype=torch.bfloat16)
+    dtokb = torch.zeros(S * Lp, D, device=dev, dtype=dt16)
     dcls, dpos, dcv = torch.zeros(D, device=dev), torch.zeros(L, D, device=dev), torch.zeros_like(cv)
     ops.embed_bwd(dpre, dtok, dtokb, dcls, dpos, dcv, cam.to(dev), cfg.sie_coe, S, B, L, D)
     d3 = dpre.reshape(S, L, D)
@@ -251,3 +266,27 @@ def test_embed_front_end(dev, hw):
     assert rel_err(dcls, d3[:, 0].sum(0)) < 1e-5
     ref_cv = torch.zeros_like(cv).index_add_(0, cam.to(dev).repeat(3), d3[:, 0] * cfg.sie_coe)
     assert rel_err(dcv, ref_cv) < 1e-5
+
+
+@pytest.mark.parametrize("n,k", [(2304, 768), (768, 768), (3072, 768), (768, 3072), (512, 768)])
+def test_gemm_error_budget_per_operand_type(dev, n, k):
+    """Where the end-to-end feature error comes from: ONE GEMM of the block on f32 activations / weights that are rounded to
+    the operand type on the way in (what the forward does to LN outputs and weights), against the exact f32 product.
+    bf16 operands (8 significant bits) cost ~2.5e-3 per GEMM, fp16 (11 bits) ~3e-4; the MFMA itself accumulates in f32
+    (the same kernels are exact to 2e-6 on representable inputs, test_gemm_nt_epilogues).  48 such GEMMs in series with a
+    residual stream that averages the errors give the 4e-3 (bf16) / 5e-4 (fp16) measured on the features."""
+    ops = _ops()
+    m = 2064
+    g = torch.Generator(device="cpu").manual_seed(n + k)
+    a = torch.randn(m, k, generator=g).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.03).to(dev)
+    ref = a.double() @ w.double().t()
+    errs = {}
+    for dt in (torch.bfloat16, torch.float16):
+        out = torch.zeros(ops.pad_rows(m), n, device=dev)
+        ops.gemm_nt(padded(a.to(dt), ops), w.to(dt), m, ops.F32, out)
+        errs[dt] = rel_err(out[:m], ref)
+    print(f"GEMM N={n} K={k}: operand-rounding error bf16 {errs[torch.bfloat16]:.2e}, fp16 {errs[torch.float16]:.2e}")
+    assert 1.5e-3 < errs[torch.bfloat16] < 3.5e-3
+    assert errs[torch.float16] < 4.5e-4
+    assert 6.0 < errs[torch.bfloat16] / errs[torch.float16] < 10.0     # 3 more mantissa bits

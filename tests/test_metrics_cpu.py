@@ -1,0 +1,149 @@
+"""Host logic of the evaluator and of the checkpoint / pretrained-weight loaders (no GPU): hand-derived CMC / mAP cases
+for eval_func (utils/metrics.py:111-170 of the reference), CLIP positional-embedding resize, weights-only loading.
+The reference's utils/metrics.py is not importable here (seaborn, scipy.integrate.simps): evaluator parity is pinned by these
+hand-derived values, not by reference outputs ("parity unpinned", see signal_amd/utils/metrics.py)."""
+import os
+import zipfile
+
+import numpy as np
+import pytest
+import torch
+
+from signal_amd.utils.metrics import R1_mAP_eval, eval_func
+
+
+def test_eval_func_hand_derived_with_same_camera_filter():
+    # 2 queries, 6 gallery items, max_rank 3; every query keeps >= 3 gallery items, so the reference's np.asarray(all_cmc) is
+    # rectangular and its result is the one derived here by hand.
+    q_pids, q_cams = np.array([1, 2]), np.array([0, 1])
+    g_pids = np.array([1, 1, 2, 3, 2, 3])
+    g_cams = np.array([0, 1, 0, 0, 1, 1])
+    dist = np.array([[0.10, 0.50, 0.30, 0.20, 0.60, 0.40],     # q0 order: g0 g3 g2 g5 g1 g4
+                     [0.40, 0.30, 0.20, 0.10, 0.05, 0.60]])    # q1 order: g4 g3 g2 g1 g0 g5
+    # q0 (pid 1, cam 0): g0 is same id + same camera -> dropped.  kept order g3 g2 g5 g1 g4 -> matches 0 0 0 1 0
+    #   cmc[:3] = 0 0 0 ; AP = (1/4) / 1 = 0.25
+    # q1 (pid 2, cam 1): g4 is same id + same camera -> dropped.  kept order g3 g2 g1 g0 g5 -> matches 0 1 0 0 0
+    #   cmc[:3] = 0 1 1 ; AP = (1/2) / 1 = 0.5
+    cmc, mAP = eval_func(dist, q_pids, g_pids, q_cams, g_cams, max_rank=3)
+    np.testing.assert_allclose(cmc, [0.0, 0.5, 0.5])
+    assert mAP == pytest.approx(0.375)
+
+
+def test_eval_func_multiple_relevant_items_average_precision():
+    q_pids, q_cams = np.array([7]), np.array([0])
+    g_pids = np.array([7, 9, 7, 7, 8])
+    g_cams = np.array([1, 1, 2, 0, 0])          # g3: same id, same camera -> dropped
+    dist = np.array([[0.3, 0.1, 0.2, 0.05, 0.4]])   # order g3 g1 g2 g0 g4 -> kept g1 g2 g0 g4 -> matches 0 1 1 0
+    # precision at the hits: 1/2, 2/3 -> AP = (1/2 + 2/3) / 2 = 7/12
+    cmc, mAP = eval_func(dist, q_pids, g_pids, q_cams, g_cams, max_rank=4)
+    np.testing.assert_allclose(cmc, [0, 1, 1, 1])
+    assert mAP == pytest.approx(7 / 12)
+
+
+def test_eval_func_short_gallery_rows_are_extended_not_ragged():
+    """Fewer than max_rank items survive q0's filter: its CMC row has 3 entries, q1's 4.  The reference stacks the rows with
+    np.asarray (metrics.py:151,167) and fails on the ragged list; here the short row is continued with its last value."""
+    q_pids, q_cams = np.array([1, 2]), np.array([0, 1])
+    g_pids, g_cams = np.array([1, 1, 2, 3]), np.array([0, 1, 0, 0])
+    dist = np.array([[0.1, 0.5, 0.3, 0.2],      # q0: drop g0; kept g3 g2 g1 -> 0 0 1 ; AP 1/3
+                     [0.4, 0.3, 0.2, 0.1]])     # q1: kept g3 g2 g1 g0 -> 0 1 0 0 ; AP 1/2
+    cmc, mAP = eval_func(dist, q_pids, g_pids, q_cams, g_cams, max_rank=50)
+    np.testing.assert_allclose(cmc, [0.0, 0.5, 1.0, 1.0])
+    assert mAP == pytest.approx((1 / 3 + 1 / 2) / 2)
+    with pytest.raises(ValueError):             # what the reference's stacking does with these rows
+        np.asarray([np.array([0, 0, 1]), np.array([0, 1, 1, 1])]).astype(np.float32)
+
+
+def test_eval_func_skips_queries_without_a_match_and_fails_when_none_has_one():
+    g_pids, g_cams = np.array([5, 6, 5]), np.array([1, 1, 2])
+    dist = np.array([[0.2, 0.1, 0.3], [0.1, 0.2, 0.3]])
+    cmc, mAP = eval_func(dist, np.array([5, 99]), g_pids, np.array([0, 0]), g_cams, max_rank=3)   # query 99 is skipped
+    np.testing.assert_allclose(cmc, [0, 1, 1])
+    assert mAP == pytest.approx((1 / 2 + 2 / 3) / 2)
+    with pytest.raises(AssertionError):
+        eval_func(dist, np.array([98, 99]), g_pids, np.array([0, 0]), g_cams)
+
+
+def test_evaluator_refuses_host_features_and_reranking():
+    from signal_amd._lib import SignalHipError
+    ev = R1_mAP_eval(2, max_rank=5, feat_norm="yes")
+    ev.update((torch.randn(4, 8), [1, 2, 1, 2], [0, 0, 1, 1], ["a", "b", "c", "d"]))
+    assert ev.img_paths == ["a", "b", "c", "d"]
+    with pytest.raises(SignalHipError):         # the distance matrix runs on the MFMA GEMM: no CPU path
+        ev.compute()
+    with pytest.raises(NotImplementedError):
+        R1_mAP_eval(2, reranking=True)
+
+
+def test_clip_positional_embedding_resize_matches_the_reference_formula():
+    """clip/model.py:712-729: CLS row kept, 14x14 grid -> h x w by bilinear interpolation (align_corners=False)."""
+    from signal_amd.modeling.clip_loader import resize_pos_embed
+    g = torch.Generator().manual_seed(0)
+    pos = torch.randn(197, 768, generator=g)
+    for h, w in ((16, 8), (8, 16)):
+        out = resize_pos_embed(pos, h, w)
+        assert out.shape == (1 + h * w, 768) and torch.equal(out[0], pos[0])
+        grid = pos[1:].reshape(1, 14, 14, 768).permute(0, 3, 1, 2)
+        want = torch.nn.functional.interpolate(grid, size=(h, w), mode="bilinear").permute(0, 2, 3, 1).reshape(h * w, 768)
+        assert torch.equal(out[1:], want)
+    assert torch.equal(resize_pos_embed(pos, 14, 14), pos)
+    with pytest.raises(ValueError):
+        resize_pos_embed(torch.randn(1 + 12, 8), 4, 2)
+
+
+def _fake_clip_state_dict(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sd = {"visual.class_embedding": torch.randn(768, generator=g), "visual.positional_embedding": torch.randn(197, 768, generator=g),
+          "visual.proj": torch.randn(768, 512, generator=g), "visual.conv1.weight": torch.randn(768, 3, 16, 16, generator=g),
+          "visual.ln_pre.weight": torch.randn(768, generator=g), "visual.ln_pre.bias": torch.randn(768, generator=g),
+          "visual.ln_post.weight": torch.randn(768, generator=g), "visual.ln_post.bias": torch.randn(768, generator=g),
+          # text tower entries must be ignored
+          "text_projection": torch.randn(512, 512, generator=g), "token_embedding.weight": torch.randn(10, 512, generator=g)}
+    p = "visual.transformer.resblocks.3."
+    sd.update({p + "attn.in_proj_weight": torch.randn(2304, 768, generator=g), p + "attn.in_proj_bias": torch.randn(2304, generator=g),
+               p + "mlp.c_fc.weight": torch.randn(3072, 768, generator=g).half()})      # CLIP checkpoints are fp16
+    return sd
+
+
+def test_clip_visual_loader_is_weights_only_and_resizes(tmp_path):
+    from signal_amd.config import get_cfg_defaults
+    from signal_amd.modeling import make_frame
+    from signal_amd.modeling.clip_loader import load_clip_visual
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "RGBNT201", "Signal.yml"))
+    model = make_frame(cfg, 171, 4, 0)
+    sd = _fake_clip_state_dict()
+    path = str(tmp_path / "clip_sd.pt")
+    torch.save(sd, path)
+    before = model.clip_vision_encoder.base.transformer.resblocks[0].mlp.c_fc.weight.detach().clone()
+    missing, unexpected = load_clip_visual(model, path, verbose=False)
+    base = model.clip_vision_encoder.base
+    assert not unexpected
+    assert "transformer.resblocks.0.mlp.c_fc.weight" in missing      # absent from the fake checkpoint: left at its init
+    assert torch.equal(base.transformer.resblocks[0].mlp.c_fc.weight, before)
+    assert base.positional_embedding.shape == (129, 768)
+    assert torch.equal(base.positional_embedding[0], sd["visual.positional_embedding"][0])
+    assert torch.equal(base.proj, sd["visual.proj"]) and torch.equal(base.conv1.weight, sd["visual.conv1.weight"])
+    w = base.transformer.resblocks[3].mlp.c_fc.weight
+    assert w.dtype == torch.float32 and torch.equal(w, sd["visual.transformer.resblocks.3.mlp.c_fc.weight"].float())
+    # a state_dict without a visual tower is refused
+    torch.save({"foo": torch.zeros(1)}, path)
+    with pytest.raises(ValueError):
+        load_clip_visual(model, path, verbose=False)
+    # a TorchScript archive (the released ViT-B-16.pt) is refused before anything is unpickled
+    ts_path = str(tmp_path / "ViT-B-16.pt")
+    with zipfile.ZipFile(ts_path, "w") as z:
+        z.writestr("archive/constants.pkl", b"")
+        z.writestr("archive/code/__torch__.py", b"")
+    with pytest.raises(ValueError, match="TorchScript"):
+        load_clip_visual(model, ts_path, verbose=False)
+    # anything that is not a plain tensor state_dict is refused by the weights-only unpickler itself
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    bad = str(tmp_path / "evil.pt")
+    torch.save({"visual.proj": Evil()}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        load_clip_visual(model, bad, verbose=False)

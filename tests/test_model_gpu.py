@@ -1,5 +1,11 @@
-"""Model-level parity on a real MI355X: signal_amd (HIP, bf16 MFMA) against the fp32 CPU oracle on the
-same PCG64-seeded weights and inputs, and SIM masks against the reference's golden fixtures."""
+"""Model-level parity on a real MI355X: signal_amd (HIP; bf16 or fp16 MFMA operands) against the fp32 CPU oracle on
+the same PCG64-seeded weights and inputs, and SIM masks against the reference's golden fixtures.
+
+Tolerances.  north_star asks 1e-3 relative on features: the fp16 operand mode (the reference's own autocast type,
+engine/processor.py:165) meets it -- measured 4.6e-4 (CLS) / 5.9e-4 (patches) -- and is asserted at 1e-3.  bf16 operands
+round to 8 bits on every GEMM input (tests/test_kernels_gpu.py::test_gemm_error_budget_per_operand_type: 2.5e-3 per GEMM);
+measured 3.8e-3 / 4.7e-3 after 12 blocks, asserted at 6e-3."""
+FEAT_TOL = {"bf16": 6e-3, "fp16": 1e-3}
 import numpy as np
 import pytest
 import torch
@@ -48,8 +54,9 @@ def build(ocfg, sd, dev, dtype="bf16"):
     return model.to(dev)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("tag", ["rgbnt201", "rgbnt100"])
-def test_inference_features_vs_oracle(dev, tag):
+def test_inference_features_vs_oracle(dev, tag, dtype):
     ocfg = O.rgbnt201_config() if tag == "rgbnt201" else O.rgbnt100_config()
     sd = O.init_state_dict(ocfg, seed=1234)
     B = 4
@@ -58,29 +65,29 @@ def test_inference_features_vs_oracle(dev, tag):
         ref = O.signal_forward_infer(sd, ocfg, img, cam)
         patches, cls = O.backbone3(sd, ocfg, img, cam)
         ref_mask, tie_free = O.sim_select(sd, patches, cls, ocfg.topk)
-    model = build(ocfg, sd, dev)
+    model = build(ocfg, sd, dev, dtype)
+    tol = FEAT_TOL[dtype]
     x = {k: v.to(dev) for k, v in img.items()}
     with torch.no_grad():
         feat = model(x, cam_label=cam.to(dev), training=False)
-        tokens, p_h, c_h = model._encode(x, cam.to(dev))
+        tokens, p_h, c_h = model._encode(x, cam.to(dev), False)
     assert feat.shape == (B, 3072)
-    # bf16 MFMA operands, fp32 accumulation / residual stream / LayerNorm / softmax.  north_star asks for 1e-3
-    # relative on bf16 features; what 12 blocks of bf16-input GEMMs give against the fp32 oracle is measured
-    # and bounded here, and reported in DESIGN.md.
+    # 16-bit MFMA operands, fp32 accumulation / residual stream / LayerNorm / softmax (module docstring: which type
+    # meets which bar)
     e_cls, e_pat = rel_err(c_h, cls), rel_err(p_h, patches)
-    print(f"[{tag}] rel err cls {e_cls:.2e} patches {e_pat:.2e} ori {rel_err(feat[:, :1536], ref[:, :1536]):.2e} "
+    print(f"[{tag} {dtype}] rel err cls {e_cls:.2e} patches {e_pat:.2e} ori {rel_err(feat[:, :1536], ref[:, :1536]):.2e} "
           f"sim {rel_err(feat[:, 1536:], ref[:, 1536:]):.2e}")
-    assert e_cls < 1e-2 and e_pat < 1e-2
-    assert rel_err(feat[:, :1536], ref[:, :1536]) < 1e-2
+    assert e_cls < tol and e_pat < tol
+    assert rel_err(feat[:, :1536], ref[:, :1536]) < tol
     # SIM output: compare where the bf16-feature masks agree with the oracle's (a flipped near-tie token changes
     # the attention input, which is a discrete effect, not an arithmetic error)
     hip_mask = torch.stack([model.SIM.token_selection.last_masks[m][..., 0] for m in O.MODALITIES]).bool().cpu()
     agree = (hip_mask == ref_mask).float().mean().item()
-    print(f"[{tag}] mask agreement with the fp32 oracle on bf16 features: {agree:.4f}")
-    assert agree > 0.97
+    print(f"[{tag} {dtype}] mask agreement with the fp32 oracle on {dtype} features: {agree:.4f}")
+    assert agree > 0.99
     same = (hip_mask == ref_mask).all(dim=2).all(dim=0)
     if same.any():
-        assert rel_err(feat[same][:, 1536:], ref[same][:, 1536:]) < 2e-2
+        assert rel_err(feat[same][:, 1536:], ref[same][:, 1536:]) < tol
 
 
 @pytest.mark.parametrize("tag", ["k80", "k112", "k64", "k80_sat"])
@@ -151,14 +158,15 @@ def test_inference_reuses_one_workspace(dev):
     assert torch.equal(f0, f1)
 
 
-@pytest.mark.parametrize("B,tag", [(1, "rgbnt201"), (7, "rgbnt201"), (3, "rgbnt100")])
-def test_inference_odd_batches_vs_oracle(dev, B, tag):
+@pytest.mark.parametrize("B,tag,dtype", [(1, "rgbnt201", "bf16"), (7, "rgbnt201", "fp16"), (3, "rgbnt100", "bf16"), (2, "rgbnt100", "fp16")])
+def test_inference_odd_batches_vs_oracle(dev, B, tag, dtype):
     """Ragged sizes: one sample (M = 387 token rows: a single partial 128-row tile, SIM with B = 1) and batches that are
     not multiples of anything; the same model instance is then reused at another batch size (workspace pools are keyed
     by shape)."""
     ocfg = O.rgbnt201_config() if tag == "rgbnt201" else O.rgbnt100_config()
     sd = O.init_state_dict(ocfg, seed=77)
-    model = build(ocfg, sd, dev)
+    model = build(ocfg, sd, dev, dtype)
+    tol = FEAT_TOL[dtype]
     for b in (B, B + 1):
         img, vid, cam = O.synthetic_batch(ocfg, b, seed=100 + b)
         with torch.no_grad():
@@ -166,12 +174,12 @@ def test_inference_odd_batches_vs_oracle(dev, B, tag):
             feat = model({k: v.to(dev) for k, v in img.items()}, cam_label=cam.to(dev), training=False)
         assert feat.shape == ref.shape == (b, 3072)
         assert torch.isfinite(feat).all()
-        assert rel_err(feat[:, :1536], ref[:, :1536]) < 1e-2
+        assert rel_err(feat[:, :1536], ref[:, :1536]) < tol
         # SIM features: compare the samples whose selection masks agree with the fp32 oracle's (see the test above)
         patches, cls = O.backbone3(sd, ocfg, img, cam)
         ref_mask, _ = O.sim_select(sd, patches, cls, ocfg.topk)
         hip_mask = torch.stack([model.SIM.token_selection.last_masks[m][..., 0] for m in O.MODALITIES]).bool().cpu()
         same = (hip_mask == ref_mask).all(dim=2).all(dim=0)
-        assert (hip_mask == ref_mask).float().mean().item() > 0.97
+        assert (hip_mask == ref_mask).float().mean().item() > 0.985
         if same.any():
-            assert rel_err(feat[same][:, 1536:], ref[same][:, 1536:]) < 2e-2
+            assert rel_err(feat[same][:, 1536:], ref[same][:, 1536:]) < tol

@@ -27,9 +27,9 @@ def tokens_from(patches, cls):
     return torch.cat([cls.unsqueeze(2), patches], dim=2).reshape(-1, patches.shape[2] + 1, patches.shape[3]).contiguous()
 
 
-def head_model(ocfg, sd, dev):
+def head_model(ocfg, sd, dev, dtype="bf16"):
     """A model whose ViT is never run (tests drive the head stages from given tokens)."""
-    model = build(ocfg, sd, dev)
+    model = build(ocfg, sd, dev, dtype)
     model.hip.prepare(dev)
     return model
 
@@ -60,48 +60,56 @@ def test_gam_vs_reference_fixture(dev, golden, tag):
         np.testing.assert_allclose(dpat[:, :, :2].cpu().numpy(), g["grad_rows"], rtol=2e-3, atol=1e-8)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("tag", ["16x8", "8x16"])
-def test_lam_vs_reference_fixture(dev, golden, tag):
+def test_lam_vs_reference_fixture(dev, golden, tag, dtype):
     from tests.golden.make_golden import head_features
     from signal_amd.modeling.hip_engine import LamFn
     g = golden(f"g5_lam_{tag}")
     ocfg = O.rgbnt201_config() if tag == "16x8" else O.rgbnt100_config()
     sd = O.init_state_dict(ocfg, seed=int(g["seed_w"]))
     patches, cls = head_features(ocfg, 4, seed=int(g["seed_x"]))
-    model = head_model(ocfg, sd, dev)
+    model = head_model(ocfg, sd, dev, dtype)
     hip = model.hip
     tok = tokens_from(patches, cls).to(dev).requires_grad_(True)
     loss = LamFn.apply(hip, 4, tok, *[hip.flat.byname[n] for n in hip.das_param_names])
     loss.backward()
-    # the two 1x1 convs run with bf16 operands: offsets / samples / loss at bf16 accuracy
+    # the two 1x1 convs run with 16-bit operands: offsets / samples / loss at that accuracy (T: fp16 rounds 8x finer)
+    T = 1.0 if dtype == "bf16" else 0.15
     ws = hip._lam_ws[(4, True)][-1]
     P = 8
     offs = ws["t"]["offs"].view(3, 4, P, 3)[0, :, :, 0].cpu().numpy().reshape(g["offsets"].shape)
-    np.testing.assert_allclose(offs, g["offsets"], rtol=0, atol=2e-2 * np.abs(g["offsets"]).max())
-    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-2)
     dpat = tok.grad.view(3, 4, 129, 512)[:, :, 1:]
-    np.testing.assert_allclose(dpat.flatten(1).norm(dim=1).cpu().numpy(), g["grad_norm"], rtol=3e-2)
     w4g = model.AlignM.DAS_r.conv_offset[4].weight.grad.reshape(-1).cpu()
-    assert cos(w4g, torch.from_numpy(g["w4_grad"])) > 0.995
-    # against the oracle's autograd for every DAS parameter
     sdo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     pr = patches.clone().requires_grad_(True)
     O.lam_loss(sdo, ocfg, pr).backward()
-    assert cos(dpat, pr.grad) > 0.995
-    for n in hip.das_param_names:
-        gh, go = hip.flat.byname[n].grad, sdo[n].grad
-        assert cos(gh, go) > 0.99, n
-        assert abs(float(gh.norm()) / float(go.norm()) - 1) < 5e-2, n
+    stats = [(n, cos(hip.flat.byname[n].grad, sdo[n].grad), abs(float(hip.flat.byname[n].grad.norm()) / float(sdo[n].grad.norm()) - 1))
+             for n in hip.das_param_names]
+    print(f"[lam {tag} {dtype}] offsets {np.abs(offs - g['offsets']).max() / np.abs(g['offsets']).max():.2e} loss "
+          f"{abs(loss.item() - float(g['loss'])) / float(g['loss']):.2e} dpatch cos {cos(dpat, pr.grad):.6f} "
+          f"param cos min {min(c for _, c, _ in stats):.6f} norm dev max {max(r for _, _, r in stats):.2e}")
+    np.testing.assert_allclose(offs, g["offsets"], rtol=0, atol=1e-2 * T * np.abs(g["offsets"]).max())
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=5e-3 * T)
+    np.testing.assert_allclose(dpat.flatten(1).norm(dim=1).cpu().numpy(), g["grad_norm"], rtol=2e-2 * T)
+    assert cos(w4g, torch.from_numpy(g["w4_grad"])) > 1 - 2e-3 * T
+    # against the oracle's autograd for every DAS parameter
+    assert cos(dpat, pr.grad) > 1 - 2e-3 * T
+    for n, c, r in stats:
+        assert c > 1 - 3e-3 * T, (n, c)
+        assert r < 3e-2 * T, (n, r)
 
 
-def test_sim_backward_vs_oracle(dev):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_sim_backward_vs_oracle(dev, dtype):
     from tests.golden.make_golden import head_features
     from signal_amd.modeling.hip_engine import SimFn
     ocfg = O.rgbnt201_config()
     sd = O.init_state_dict(ocfg, seed=31)
     patches, cls = head_features(ocfg, 8, seed=32)
-    model = head_model(ocfg, sd, dev)
+    model = head_model(ocfg, sd, dev, dtype)
     hip = model.hip
+    T = 1.0 if dtype == "bf16" else 0.15
     tok = tokens_from(patches, cls).to(dev).requires_grad_(True)
     out, mask = SimFn.apply(hip, 8, tok, *[hip.flat.byname[n] for n in hip.sim_param_names])
     w = torch.randn(8, 1536, generator=torch.Generator().manual_seed(3))
@@ -111,27 +119,34 @@ def test_sim_backward_vs_oracle(dev):
     ref, rmask, _ = O.sim_forward(sdo, ocfg, pr, cr)
     (ref * w).sum().backward()
     assert torch.equal(mask.bool().cpu(), rmask)
-    assert rel_err(out, ref) < 1e-2
     g4 = tok.grad.view(3, 8, 129, 512)
-    assert cos(g4[:, :, 1:], pr.grad) > 0.995 and cos(g4[:, :, 0], cr.grad) > 0.995
-    assert abs(float(g4[:, :, 1:].norm()) / float(pr.grad.norm()) - 1) < 3e-2
-    for n in hip.sim_param_names:
-        gh, go = hip.flat.byname[n].grad, sdo[n].grad
-        assert cos(gh, go) > 0.99, n
-        assert abs(float(gh.norm()) / float(go.norm()) - 1) < 5e-2, n
+    stats = [(n, cos(hip.flat.byname[n].grad, sdo[n].grad), abs(float(hip.flat.byname[n].grad.norm()) / float(sdo[n].grad.norm()) - 1))
+             for n in hip.sim_param_names]
+    print(f"[sim bwd {dtype}] out {rel_err(out, ref):.2e} dpatch cos {cos(g4[:, :, 1:], pr.grad):.6f} dcls cos {cos(g4[:, :, 0], cr.grad):.6f} "
+          f"param cos min {min(c for _, c, _ in stats):.6f} norm dev max {max(r for _, _, r in stats):.2e}")
+    assert rel_err(out, ref) < 6e-3 * T
+    assert cos(g4[:, :, 1:], pr.grad) > 1 - 2e-3 * T and cos(g4[:, :, 0], cr.grad) > 1 - 2e-3 * T
+    assert abs(float(g4[:, :, 1:].norm()) / float(pr.grad.norm()) - 1) < 2e-2 * T
+    for n, c, r in stats:
+        assert c > 1 - 3e-3 * T, (n, c)
+        assert r < 3e-2 * T, (n, r)
     for n in ("SIM.token_selection.W_q.weight", "SIM.token_selection.W_k.weight", "SIM.token_selection.W_v.weight"):
         assert hip.flat.byname[n].grad is None      # dead / selection-only parameters (useA.py:46-48)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("tag", ["rgbnt201", "rgbnt100"])
-def test_full_train_step_vs_oracle(dev, golden, tag):
-    """Loss terms and every parameter gradient of one training iteration at real size (B=8: 2 ids x 4)."""
+def test_full_train_step_vs_oracle(dev, golden, tag, dtype):
+    """Loss terms and every parameter gradient of one training iteration at real size (B=8: 2 ids x 4), both operand types.
+    fp16 (the north_star bar): loss terms <= 1e-3 of the reference fixture, every parameter's gradient cos >= 0.999.
+    Measured (tools/dtype_probe.py): fp16 losses 1-4e-5, whole-gradient cos 0.999999, worst parameter 0.99982;
+    bf16 losses 2e-4, whole-gradient cos 0.99995, worst parameter 0.99967."""
     from signal_amd.layers.make_loss import make_loss, total_loss
     g = golden(f"g7_step_{tag}")
     ocfg = O.rgbnt201_config(num_instance=4) if tag == "rgbnt201" else O.rgbnt100_config(num_instance=4)
     sd = O.init_state_dict(ocfg, seed=int(g["seed"]), head_scale=30.0)
     img, vid, cam = O.synthetic_batch(ocfg, 8, seed=int(g["seed"]))
-    model = build(ocfg, sd, dev)
+    model = build(ocfg, sd, dev, dtype)
     model.train()
     cfg = model.cfg
     loss_fn, _ = make_loss(cfg, ocfg.num_classes)
@@ -139,14 +154,17 @@ def test_full_train_step_vs_oracle(dev, golden, tag):
                 sge=ocfg.stage)
     assert out[0] == 3 and len(out) == (7 if ocfg.direct else 11)
     loss = total_loss(cfg, out, loss_fn, vid.to(dev), cam.to(dev), ocfg.stage)
-    loss.backward()
-    # ---- forward quantities against the REFERENCE's fixture (fp32), at bf16 accuracy ----
-    np.testing.assert_allclose(out[-2].item(), float(g["gam"]), rtol=2e-2)
-    np.testing.assert_allclose(out[-1].item(), float(g["lam"]), rtol=2e-2)
-    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-2)
+    # fp16 backward signals need the loss scaled (the train engine uses a dynamic scale; a fixed one here)
+    scale = 1024.0 if dtype == "fp16" else 1.0
+    loss.backward(gradient=torch.tensor(scale, device=dev))
+    # ---- forward quantities against the REFERENCE's fixture (fp32) ----
+    ltol = 1e-3 if dtype == "fp16" else 2e-3
+    np.testing.assert_allclose(out[-2].item(), float(g["gam"]), rtol=ltol)
+    np.testing.assert_allclose(out[-1].item(), float(g["lam"]), rtol=ltol)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=ltol)
     hip_mask = torch.stack([model.SIM.token_selection.last_masks[m][..., 0] for m in O.MODALITIES]).cpu().numpy()
     agree = (hip_mask.astype(np.int8) == g["masks"]).mean()
-    assert agree > 0.97, agree
+    assert agree > 0.995, agree
     # ---- gradients against the reference's per-parameter norms and the oracle's full gradients ----
     sdo = {k: v.clone() for k, v in sd.items()}
     for k, v in sdo.items():
@@ -164,12 +182,12 @@ def test_full_train_step_vs_oracle(dev, golden, tag):
     for k, rn in ref_norm.items():
         if k in frozen:
             continue
-        gh, go = named[k].grad, sdo[k].grad
+        gh, go = named[k].grad / scale, sdo[k].grad
         if rn < 1e-5:       # exactly-zero gradients in exact arithmetic (bias in front of a BatchNorm)
             continue
         c, ratio = cos(gh, go), float(gh.norm()) / rn
-        if c < 0.98 or abs(ratio - 1) > 8e-2:
-            bad.append((k, round(c, 4), round(ratio, 4)))
+        if c < 0.999 or abs(ratio - 1) > (2e-2 if dtype == "fp16" else 5e-2):
+            bad.append((k, round(c, 5), round(ratio, 4)))
     assert not bad, bad
 
 
@@ -266,3 +284,129 @@ def test_bnneck_classifier_hip_vs_torch(dev, B, F, C):
     assert bn_h.bias.grad is None
     assert rel_err(bn_h.running_mean, bn_t.running_mean) < 1e-5 and rel_err(bn_h.running_var, bn_t.running_var) < 1e-5
     assert int(bn_h.num_batches_tracked) == 1
+
+
+def _small_train_setup(dev, dtype="bf16", stage=None, on_cpu_optimizer=False, seed=41):
+    from signal_amd.modeling import make_frame
+    from signal_amd.solver.make_optimizer import make_optimizer
+    from tests.test_model_gpu import make_cfg
+    ocfg = O.rgbnt201_config(num_instance=2)
+    sd = O.init_state_dict(ocfg, seed=seed, head_scale=30.0)
+    cfg = make_cfg(ocfg, dtype)
+    cfg.SOLVER.OPTIMIZER_NAME, cfg.SOLVER.BASE_LR = "Adam", 3.5e-4
+    if stage is not None:
+        cfg.MODEL.stageName = stage
+    model = make_frame(cfg, ocfg.num_classes, ocfg.camera_num, 0)
+    model.load_state_dict(sd, strict=False)
+    opt = None
+    if on_cpu_optimizer:                      # the reference's train.py order: optimizer first, model.to(device) later
+        opt = make_optimizer(cfg, model, None)[0]
+        assert type(opt) is torch.optim.Adam
+    model.to(dev)
+    img, vid, cam = O.synthetic_batch(ocfg, 4, seed=seed + 1)
+    batch = ({k: v.to(dev) for k, v in img.items()}, vid.to(dev), cam.to(dev))
+    return ocfg, sd, cfg, model, opt, batch
+
+
+def test_train_step_adopts_an_optimizer_built_on_the_cpu_model(dev):
+    """train.py calls make_optimizer before the model moves to the GPU, so do_train receives a plain
+    torch.optim.Adam.  TrainStep must (a) run it as the fused kernel with the SAME param_groups (the scheduler keeps steering
+    them), (b) leave the gradient-less selection weights W_q / W_k / W_v bit-unchanged (no weight decay on a zero gradient),
+    (c) produce the same parameters as the path whose optimizer was fused from the start."""
+    from signal_amd.engine.trainer import TrainStep
+    from signal_amd.solver.make_optimizer import FusedAdam
+    from signal_amd.solver.scheduler_factory import create_scheduler
+    ocfg, sd, cfg, model, opt, batch = _small_train_setup(dev, on_cpu_optimizer=True)
+    sched = create_scheduler(cfg, opt)
+    ts = TrainStep(cfg, model, num_classes=ocfg.num_classes, optimizer=opt)
+    assert isinstance(ts.optimizer, FusedAdam) and ts.optimizer.param_groups is opt.param_groups
+    sched.step(1)
+    lr_now = [g["lr"] for g in opt.param_groups]
+    for _ in range(2):
+        ts.step(*batch)
+    torch.cuda.synchronize()
+    assert [g["lr"] for g in ts.optimizer.param_groups] == lr_now
+    for n in ("W_q", "W_k", "W_v"):
+        for part in ("weight", "bias"):
+            k = f"SIM.token_selection.{n}.{part}"
+            assert model.hip.flat.byname[k].grad is None
+            assert torch.equal(model.state_dict()[k].cpu(), sd[k]), k
+    # the frozen BNNeck biases stay put as well
+    assert torch.equal(model.bottleneck.bias.detach().cpu(), sd["bottleneck.bias"])
+    # twin: optimizer built on the GPU model (fused from the start), same schedule
+    ocfg2, _, cfg2, model2, _, batch2 = _small_train_setup(dev)
+    ts2 = TrainStep(cfg2, model2, num_classes=ocfg2.num_classes)
+    create_scheduler(cfg2, ts2.optimizer).step(1)
+    for _ in range(2):
+        ts2.step(*batch2)
+    torch.cuda.synchronize()
+    a, b = model.hip.flat.data, model2.hip.flat.data
+    assert rel_err(a, b) < 1e-5
+    w = "clip_vision_encoder.base.transformer.resblocks.0.mlp.c_fc.weight"
+    assert not torch.equal(model.state_dict()[w].cpu(), sd[w])
+
+
+def test_stage_cls_leaves_the_sampler_parameters_untouched(dev):
+    """In stage 'CLS' only GAM runs (useB.py:181-184): AlignM.DAS_* get no gradient in the reference (grad None), so Adam
+    must not touch them -- not even with weight decay."""
+    from signal_amd.engine.trainer import TrainStep
+    ocfg, sd, cfg, model, _, batch = _small_train_setup(dev, stage="CLS")
+    ts = TrainStep(cfg, model, num_classes=ocfg.num_classes)
+    for _ in range(2):
+        loss = ts.step(*batch)
+    assert len(ts.last_output) == 6 and torch.isfinite(loss)
+    for k, v in model.state_dict().items():
+        if k.startswith("AlignM.DAS_"):
+            assert torch.equal(v.cpu(), sd[k]), k
+    assert not torch.equal(model.state_dict()["AlignM.contra_temp"].cpu(), sd["AlignM.contra_temp"])
+
+
+def test_fp16_train_step_with_device_loss_scaler(dev):
+    """fp16 operands + the device-resident GradScaler: clean steps apply and count, an overflowing step is skipped (parameters,
+    moments, operand mirror bit-unchanged), the scale backs off, and growth doubles it after `growth_interval` clean steps."""
+    from signal_amd.engine.trainer import TrainStep
+    ocfg, sd, cfg, model, _, batch = _small_train_setup(dev, dtype="fp16")
+    ts = TrainStep(cfg, model, num_classes=ocfg.num_classes)
+    assert ts.scaler is not None and model.hip.flat.op16.dtype == torch.float16
+    ts.scaler.growth_interval = 3
+    l0 = float(ts.step(*batch))
+    l1 = float(ts.step(*batch))
+    st = ts.scaler.state.cpu().tolist()
+    assert st[0] == 65536.0 and st[2] == 0.0 and st[3] == 2.0 and st[4] == 2.0, st
+    assert l1 < l0                                   # it trains
+    # gradient magnitudes are the unscaled ones: compare one step against the bf16 engine on the same weights / batch
+    p_before = model.hip.flat.data.clone()
+    m_before, mirror_before = ts.optimizer.m.clone(), model.hip.flat.op16.clone()
+    # force an overflow: a scale so large that the f16 backward signals saturate
+    ts.scaler.state[0] = 2.0 ** 60
+    ts.scaler.state[1] = 2.0 ** -60
+    ts.step(*batch)
+    st = ts.scaler.state.cpu().tolist()
+    assert st[0] == 2.0 ** 59 and st[3] == 0.0 and st[4] == 2.0, st        # backed off, tracker reset, no step counted
+    assert torch.equal(model.hip.flat.data, p_before) and torch.equal(ts.optimizer.m, m_before)
+    assert torch.equal(model.hip.flat.op16, mirror_before)
+    # back to a sane scale: three clean steps -> one growth
+    ts.scaler.state[0] = 1024.0
+    ts.scaler.state[1] = 1.0 / 1024.0
+    for _ in range(3):
+        ts.step(*batch)
+    st = ts.scaler.state.cpu().tolist()
+    assert st[0] == 2048.0 and st[3] == 0.0 and st[4] == 5.0, st
+    assert not torch.equal(model.hip.flat.data, p_before)
+    assert torch.isfinite(model.hip.flat.data).all()
+
+
+def test_fp16_and_bf16_engines_take_the_same_first_step(dev):
+    """One Adam step from the same weights on the same batch: the fp16 engine (scaled backward, unscale in the optimizer)
+    and the bf16 engine must move the parameters the same way (Adam's first step is lr * sign-like: compare directions)."""
+    from signal_amd.engine.trainer import TrainStep
+    res = {}
+    for dtype in ("bf16", "fp16"):
+        ocfg, sd, cfg, model, _, batch = _small_train_setup(dev, dtype=dtype)
+        ts = TrainStep(cfg, model, num_classes=ocfg.num_classes)
+        before = model.hip.flat.data.clone()
+        ts.step(*batch)
+        res[dtype] = (model.hip.flat.data - before).cpu()
+    a, b = res["bf16"], res["fp16"]
+    live = (a != 0) | (b != 0)
+    assert cos(a[live], b[live]) > 0.97
