@@ -133,8 +133,10 @@ typedef struct SigEmbedActs {
 typedef struct SigEmbedGrads {
     float *w_conv, *class_embedding, *positional_embedding, *cv_embed, *ln_w, *ln_b;
 } SigEmbedGrads;
-int sig_embed_fwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedActs* a, const float* img,
-                  const int64_t* cam_label, int img_h, int img_w, int patch, void* stream);
+/* img_parts[i]: f32 [S/n_parts, 3, img_h, img_w] (contiguous) = the images of sequences i*S/n_parts .. : the three modality
+ * tensors the reference passes to its three backbone calls, read in place */
+int sig_embed_fwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedActs* a, const float* const* img_parts,
+                  int n_parts, const int64_t* cam_label, int img_h, int img_w, int patch, void* stream);
 /* dx0: f32 [M,D] gradient of x0; scratch_dpre f32 [M,D]; scratch_dtok bf16 [S*(L-1) padded, D] (pad rows zero) */
 int sig_embed_bwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedActs* a, const SigEmbedGrads* g,
                   const float* dx0, float* scratch_dpre, uint16_t* scratch_dtok, const int64_t* cam_label,

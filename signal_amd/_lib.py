@@ -85,7 +85,7 @@ SIGNATURES.update({
     "sig_lam_fwd": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "sig_lam_bwd": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sig_embed_assemble_bwd": SIGNATURES.pop("sig_embed_bwd"),
-    "sig_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sig_embed_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "sig_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sig_block_fwd": [_vp, _vp, _vp, _vp],
     "sig_block_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],

@@ -51,6 +51,35 @@ __device__ __forceinline__ float gelu_erf_grad_f(float u) {
 //    exchange is an involution).
 // Rows >= M are computed (the swaps need every lane) but neither loaded, stored nor summed.
 // ------------------------------------------------------------------------------------------------
+// Output stores of the epilogues go through a buffer descriptor so that they can carry a cache policy (aux bits of
+// buffer_store: 16 = sc1, 2 = nt, 0 = default).  A tile's output (128-256 KB per 256x256 tile, never re-read by this
+// kernel) otherwise write-allocates in the XCD's 4 MB L2 next to the operand panels the resident blocks keep re-reading;
+// sc1 stores are write-through and DROP the line (MI355X_MICROARCH.md, stores of each flavour).
+// Measured per epilogue at M = 24768 (tools/ab_kernels.sh, same box, plain / sc1 / nt in us): qkv (bias, 16-bit out)
+// 96.5 / 94.0 / 100; c_fc 148 / 141-152 / 151; GELU' dgrad 152 / 160 / 139; f32 + residual outputs 50.5 / 66 / 51 and
+// 118 / 133 / 120 (sc1 doubles WRITE_SIZE there: the residual lines are read and rewritten).  So: sc1 for the plain
+// 16-bit projection outputs, nt for the GELU' dgrad, default for everything else.  L2-miss traffic of c_fc moved only
+// 187 -> 156 MB: the operand re-fetches come from sibling blocks drifting apart in time, not from output pollution, and
+// are served by the 256 MB Infinity Cache (A + W = 43 MB).
+#ifdef SIG_STORE_AUX
+template <int EPI> constexpr int store_aux() { return SIG_STORE_AUX; }      // A/B builds: one policy everywhere
+#else
+template <int EPI> constexpr int store_aux() { return EPI == SIG_EPI_BIAS_BF16 ? 16 : (EPI == SIG_EPI_DGELU_BF16 ? 2 : 0); }
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);   // raw buffer, byte offsets, no swizzle
+}
+template <int AUX>
+__device__ __forceinline__ void store16_policy(__amdgpu_buffer_rsrc_t r, void* base, size_t elem_off_bytes, uint4 v) {
+    if constexpr (AUX == 0) {
+        *(uint4*)((char*)base + elem_off_bytes) = v;
+    } else {
+        const u32x4_t w = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(w, r, (int)elem_off_bytes, 0, AUX);
+    }
+}
+
 __device__ __forceinline__ void lane_swap16(uint32_t& a, uint32_t& b) {
     const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
     a = r[0];
@@ -78,6 +107,7 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
     for (int j = 0; j < TN; ++j) csum[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bool save_u = GELU_FWD && p.aux != nullptr;
     const bool do_sum = p.colsum != nullptr;
+    const __amdgpu_buffer_rsrc_t r_out = out_rsrc(p.out), r_aux = out_rsrc(p.aux);
     // GELU': the whole tile's saved pre-activations are requested before anything is consumed (TM*TN/2 16-B loads per
     // lane, in the registers the operand fragments no longer need) -- inside the store loop their latency was exposed
     // once per 16-row group
@@ -125,7 +155,7 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
                 }
             }
             if (OUT_F32) {
-                if (live) *(f32x4_t*)((float*)p.out + (size_t)m * p.ldo + nc + j * 16) = x;
+                if (live) store16_policy<store_aux<EPI>()>(r_out, p.out, ((size_t)m * p.ldo + nc + j * 16) * 4, __builtin_bit_cast(uint4, x));
             } else {
                 pk[j][0] = pack2_t<DT>(x[0], x[1]);
                 pk[j][1] = pack2_t<DT>(x[2], x[3]);
@@ -138,8 +168,8 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
                 lane_swap16(pk[2 * jp][0], pk[2 * jp + 1][0]);
                 lane_swap16(pk[2 * jp][1], pk[2 * jp + 1][1]);
                 if (live)
-                    *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + ns + jp * 32) =
-                        make_uint4(pk[2 * jp][0], pk[2 * jp][1], pk[2 * jp + 1][0], pk[2 * jp + 1][1]);
+                    store16_policy<store_aux<EPI>()>(r_out, p.out, ((size_t)m * p.ldo + ns + jp * 32) * 2,
+                                   make_uint4(pk[2 * jp][0], pk[2 * jp][1], pk[2 * jp + 1][0], pk[2 * jp + 1][1]));
             }
         }
         if (GELU_FWD) {
@@ -148,8 +178,8 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
                 lane_swap16(pu[2 * jp][0], pu[2 * jp + 1][0]);
                 lane_swap16(pu[2 * jp][1], pu[2 * jp + 1][1]);
                 if (live && save_u)
-                    *(uint4*)((bf16_t*)p.aux + (size_t)m * p.ldaux + ns + jp * 32) =
-                        make_uint4(pu[2 * jp][0], pu[2 * jp][1], pu[2 * jp + 1][0], pu[2 * jp + 1][1]);
+                    store16_policy<store_aux<EPI>()>(r_aux, p.aux, ((size_t)m * p.ldaux + ns + jp * 32) * 2,
+                                   make_uint4(pu[2 * jp][0], pu[2 * jp][1], pu[2 * jp + 1][0], pu[2 * jp + 1][1]));
             }
         }
     }
@@ -312,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
         f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
         if (HAS_BIAS) { b0 = *(const f32x4_t*)(p.bias + n); b1 = *(const f32x4_t*)(p.bias + n + 4); }
         f32x4_t cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
+        const __amdgpu_buffer_rsrc_t r_out = out_rsrc(p.out);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -324,9 +355,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
                 f32x4_t v0 = *(const f32x4_t*)(stg + row * 68 + t8 * 8) + b0, v1 = *(const f32x4_t*)(stg + row * 68 + t8 * 8 + 4) + b1;
                 if (m >= p.M) continue;
                 if (HAS_RES) { v0 += rres[HAS_RES ? i : 0][q][0]; v1 += rres[HAS_RES ? i : 0][q][1]; }
-                float* o = (float*)p.out + (size_t)m * p.ldo + n;
-                *(f32x4_t*)o = v0;
-                *(f32x4_t*)(o + 4) = v1;
+                const size_t ob = ((size_t)m * p.ldo + n) * 4;
+                store16_policy<store_aux<EPI>()>(r_out, p.out, ob, __builtin_bit_cast(uint4, v0));
+                store16_policy<store_aux<EPI>()>(r_out, p.out, ob + 16, __builtin_bit_cast(uint4, v1));
                 cs0 += v0;
                 cs1 += v1;
             }

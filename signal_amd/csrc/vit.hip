@@ -45,17 +45,22 @@ extern "C" {
 // ------------------------------------------------------------------------------------------------
 // embed: im2col -> conv1 as GEMM -> +CLS/camera/positional -> ln_pre
 // ------------------------------------------------------------------------------------------------
-int sig_embed_fwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedActs* a, const float* img,
+int sig_embed_fwd(const SigVitDims* d, const SigEmbedParams* p, const SigEmbedActs* a, const float* const* img_parts, int n_parts,
                   const int64_t* cam_label, int img_h, int img_w, int patch, void* stream) {
     RUN(check_dims(d, "embed_fwd"));
-    SIG_CHECK_ARG(p && a && img, "embed_fwd: null argument");
+    SIG_CHECK_ARG(p && a && img_parts && n_parts > 0 && d->S % n_parts == 0, "embed_fwd: null argument / image parts must divide S");
+    for (int i = 0; i < n_parts; ++i) SIG_CHECK_ARG(img_parts[i], "embed_fwd: image part %d is null", i);
     SIG_CHECK_ARG(patch > 0 && (img_h / patch) * (img_w / patch) == d->L - 1, "embed_fwd: %dx%d / %d does not give %d patches",
                   img_h, img_w, patch, d->L - 1);
     hipStream_t st = (hipStream_t)stream;
     const int dt = d->dtype;
     const int K = 3 * patch * patch, Mt = d->S * (d->L - 1);
     SIG_CHECK_ARG((K & 63) == 0, "embed_fwd: 3*P*P must be a multiple of 64");
-    RUN(sig_launch_im2col(img, a->patches, d->S, img_h, img_w, patch, dt, st));
+    // one gather per modality straight from the caller's tensors (the reference's three backbone calls, make_model.py:181-183,
+    // become row ranges of ONE patch matrix): no staging copy of the 75 MB of f32 images
+    const int per = d->S / n_parts;
+    for (int i = 0; i < n_parts; ++i)
+        RUN(sig_launch_im2col(img_parts[i], a->patches + (size_t)i * per * (d->L - 1) * K, per, img_h, img_w, patch, dt, st));
     RUN(sig_launch_gemm_nt(nt(dt, a->patches, K, p->w_conv, K, Mt, d->D, K, a->tok, d->D), SIG_EPI_F32, st));
     RUN(sig_launch_embed_assemble(a->tok, p->class_embedding, p->positional_embedding, p->cv_embed, cam_label, p->sie_coe,
                                   p->ln_w, p->ln_b, a->x0, a->pre_ln, a->mean, a->rstd, d->S, d->B, d->L, d->D, 1e-5f, st));

@@ -339,7 +339,6 @@ class HipPath:
         w = _Ws(dev)
         ws = {"S": S, "B": B, "M": M, "train": train}
         ws["dims"] = _lib.SigVitDims(S, B, L, D, H, Fd, O, self.dt)
-        ws["img"] = torch.empty(S, 3, *self.img_hw, dtype=F32, device=dev)
         ws["patches"], ws["tok"] = w.z(Mt, K, BF), w.z(Mt, D)
         ws["pre_ln"] = w.z(M, D) if train else None
         ws["emean"], ws["erstd"] = (w.v(M), w.v(M)) if train else (None, None)
@@ -383,24 +382,27 @@ class HipPath:
         B = imgs[0].shape[0]
         S = len(imgs) * B
         ws = self._get_ws(self._vit_ws, (S, B, train), lambda: self._alloc_vit(S, B, train))
-        for i, im in enumerate(imgs):
-            if im.shape[1:] != (3, *self.img_hw):
-                raise ValueError(f"expected images [B,3,{self.img_hw[0]},{self.img_hw[1]}], got {tuple(im.shape)}")
-            ws["img"][i * B:(i + 1) * B].copy_(im)
+        for im in imgs:
+            if tuple(im.shape) != (B, 3, *self.img_hw) or im.dtype != F32 or not im.is_contiguous():
+                raise ValueError(f"expected contiguous f32 images [{B},3,{self.img_hw[0]},{self.img_hw[1]}], got {tuple(im.shape)} {im.dtype}")
         ws["cam"] = cam
         st = _stream()
         d = ref(ws["dims"])
-        _lib.call("sig_embed_fwd", d, ref(self.embed_p), ref(ws["embed_a"]), ws["img"].data_ptr(),
+        import ctypes
+        parts = (ctypes.c_void_p * len(imgs))(*[im.data_ptr() for im in imgs])     # read in place: no staging copy
+        _lib.call("sig_embed_fwd", d, ref(self.embed_p), ref(ws["embed_a"]), ctypes.cast(parts, ctypes.c_void_p), len(imgs),
                   None if cam is None else cam.data_ptr(), self.img_hw[0], self.img_hw[1], self.patch, st)
+        if train:
+            ws["dtokens"].zero_()       # the heads' backward stages accumulate the token gradient here (shared_dtokens)
         for i in range(self.layers):
             _lib.call("sig_block_fwd", d, ref(self.block_p[i]), ref(ws["block_a"][i]), st)
         _lib.call("sig_head_fwd", d, ref(self.head_p), ref(ws["head_a"]), st)
         return ws
 
-    def vit_backward(self, ws, dtokens: torch.Tensor):
-        """dtokens [S,L,out] -> accumulates every ViT parameter gradient into flat.grad."""
-        M, st, d = ws["M"], _stream(), ref(ws["dims"])
-        ws["dtokens"][:M].copy_(dtokens.reshape(M, self.out_dim))
+    def vit_backward(self, ws):
+        """ws["dtokens"] (the gradient of the token tensor, accumulated by the consumers) -> accumulates every ViT parameter
+        gradient into flat.grad."""
+        st, d = _stream(), ref(ws["dims"])
         _lib.call("sig_head_bwd", d, ref(self.head_p), ref(ws["head_a"]), ref(self.head_g), ws["dtokens"].data_ptr(),
                   ws["dtok_b"].data_ptr(), ws["dh"].data_ptr(), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(),
                   self.b_proj_grad[self.layers - 1].data_ptr(), st)
@@ -416,6 +418,17 @@ class HipPath:
                   ws["dpre"].data_ptr(), ws["dtok_e"].data_ptr(), None if cam is None else cam.data_ptr(), self.patch, st)
 
     on_block_grads_ready = None  # hook for the data-parallel reducer (signal_amd/parallel)
+
+    # The token tensor handed out by a TRAINING forward and the buffer that collects its gradient.  SIM / GAM / LAM
+    # backward accumulate straight into that buffer when their input IS this tensor (they return no gradient to autograd),
+    # instead of each zero-filling a 50 MB tensor that autograd then adds up and the backbone copies once more.
+    _live_tokens = None
+
+    def shared_dtokens(self, tokens: torch.Tensor):
+        lt = self._live_tokens
+        if lt is not None and lt[0] == tokens.data_ptr() and tuple(tokens.shape) == lt[1]:
+            return lt[2]
+        return None
 
     # ------------------------------------------------------------------ SIM
     def _alloc_sim(self, B, train):
@@ -513,21 +526,34 @@ class BackboneFn(torch.autograd.Function):
         train = hip.grad_mode and any(ctx.needs_input_grad)   # see HipPath.grad_mode
         ws = hip.vit_forward(list(imgs), cam, train)
         ctx.hip, ctx.ws, ctx.n_img, ctx.train, ctx.lease = hip, ws, n_img, train, _WsLease(ws)
+        ctx.set_materialize_grads(False)
         M = ws["M"]
-        out = ws["tokens"][:M].view(ws["S"], hip.L, hip.out_dim).clone()
+        view = ws["tokens"][:M].view(ws["S"], hip.L, hip.out_dim)
+        cls = view[:, 0].clone()                     # [S, out]: the ReID heads read only these rows
         if not train:
+            out = view.clone()                       # the inference workspace goes back to the pool right away
             ctx.lease.release()
-        return out
+            return out, cls
+        # training: the workspace is held until backward, so the tokens are handed out in place (no 50 MB clone)
+        hip._live_tokens = (view.data_ptr(), tuple(view.shape), ws["dtokens"][:M].view(ws["S"], hip.L, hip.out_dim))
+        return view, cls
 
     @staticmethod
-    def backward(ctx, dtokens):
+    def backward(ctx, dtokens, dcls):
         hip, ws = ctx.hip, ctx.ws
+        acc = ws["dtokens"][:ws["M"]].view(ws["S"], hip.L, hip.out_dim)
+        if dtokens is not None:                      # a consumer that went through plain autograd
+            acc.add_(dtokens)
+        if dcls is not None:
+            acc[:, 0].add_(dcls)
+        if hip._live_tokens is not None and hip._live_tokens[2].data_ptr() == acc.data_ptr():
+            hip._live_tokens = None
         if hip.direct_grads:
-            hip.vit_backward(ws, dtokens.contiguous())
+            hip.vit_backward(ws)
             grads = (None,) * len(hip.vit_param_names)
         else:
             hip.zero_grads_of("clip_vision_encoder.")
-            hip.vit_backward(ws, dtokens.contiguous())
+            hip.vit_backward(ws)
             grads = hip.grads_of("clip_vision_encoder.", hip.vit_param_names)
         ctx.lease.release()
         return (None, None, None) + (None,) * ctx.n_img + grads
@@ -542,6 +568,7 @@ class SimFn(torch.autograd.Function):
         tok = tokens.contiguous()   # read row-wise only, so it needs no row padding
         ws = hip.sim_forward(tok, B, train)
         ctx.hip, ctx.ws, ctx.B, ctx.shape, ctx.lease = hip, ws, B, tokens.shape, _WsLease(ws)
+        ctx.acc = hip.shared_dtokens(tokens) if train else None
         out = ws["t"]["out"][:3 * B].reshape(B, 3 * 512).clone()
         mask = ws["t"]["mask_f"].view(3, B, hip.L - 1).clone()
         ctx.mark_non_differentiable(mask)
@@ -552,7 +579,8 @@ class SimFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dmask):
         hip, ws = ctx.hip, ctx.ws
-        dtokens = torch.zeros(ctx.shape, dtype=F32, device=dout.device)
+        shared = ctx.acc is not None
+        dtokens = ctx.acc if shared else torch.zeros(ctx.shape, dtype=F32, device=dout.device)
         if hip.direct_grads:
             hip.sim_backward(ws, dout.contiguous(), dtokens)
             grads = (None,) * len(hip.sim_param_names)
@@ -561,7 +589,7 @@ class SimFn(torch.autograd.Function):
             hip.sim_backward(ws, dout.contiguous(), dtokens)
             grads = hip.grads_of("SIM.modal_interactive.", hip.sim_param_names)
         ctx.lease.release()
-        return (None, None, dtokens) + grads
+        return (None, None, None if shared else dtokens) + grads
 
 
 class GamFn(torch.autograd.Function):
@@ -572,6 +600,7 @@ class GamFn(torch.autograd.Function):
         tok = tokens.contiguous()
         ws = hip.gam_forward(tok, B)
         ctx.hip, ctx.ws, ctx.shape, ctx.lease = hip, ws, tokens.shape, _WsLease(ws)
+        ctx.acc = hip.shared_dtokens(tokens) if hip.grad_mode else None
         out = ws["t"]["loss"][0].clone()
         if not (hip.grad_mode and any(ctx.needs_input_grad)):   # no backward will come: hand the workspace back now
             ctx.lease.release()
@@ -580,7 +609,8 @@ class GamFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         hip, ws = ctx.hip, ctx.ws
-        dtokens = torch.zeros(ctx.shape, dtype=F32, device=dloss.device)
+        shared = ctx.acc is not None
+        dtokens = ctx.acc if shared else torch.zeros(ctx.shape, dtype=F32, device=dloss.device)
         if hip.direct_grads:
             hip.gam_backward(ws, dloss.contiguous().reshape(1), dtokens)
             dtemp = None
@@ -589,7 +619,7 @@ class GamFn(torch.autograd.Function):
             hip.gam_backward(ws, dloss.contiguous().reshape(1), dtokens)
             dtemp = hip._g("AlignM.contra_temp").clone()
         ctx.lease.release()
-        return None, None, dtokens, dtemp
+        return None, None, None if shared else dtokens, dtemp
 
 
 class LamFn(torch.autograd.Function):
@@ -601,6 +631,7 @@ class LamFn(torch.autograd.Function):
         tok = tokens.contiguous()
         ws = hip.lam_forward(tok, B, train)
         ctx.hip, ctx.ws, ctx.tok, ctx.lease = hip, ws, tok, _WsLease(ws)
+        ctx.acc = hip.shared_dtokens(tok) if train else None
         out = ws["t"]["loss"][0].clone()
         if not train:
             ctx.lease.release()
@@ -609,7 +640,8 @@ class LamFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         hip, ws = ctx.hip, ctx.ws
-        dtokens = torch.zeros(ctx.tok.shape, dtype=F32, device=dloss.device)
+        shared = ctx.acc is not None
+        dtokens = ctx.acc if shared else torch.zeros(ctx.tok.shape, dtype=F32, device=dloss.device)
         if hip.direct_grads:
             hip.lam_backward(ws, ctx.tok, dloss.contiguous().reshape(1), dtokens)
             grads = (None,) * len(hip.das_param_names)
@@ -618,4 +650,4 @@ class LamFn(torch.autograd.Function):
             hip.lam_backward(ws, ctx.tok, dloss.contiguous().reshape(1), dtokens)
             grads = hip.grads_of("AlignM.DAS_", hip.das_param_names)
         ctx.lease.release()
-        return (None, None, dtokens) + grads
+        return (None, None, None if shared else dtokens) + grads

@@ -120,9 +120,10 @@ class Signal(nn.Module):
         vit_params = [hip.flat.byname[n] for n in hip.vit_param_names]
         # training=False never differentiates: take the (small, ping-pong) inference workspace even under grad mode
         hip.grad_mode = torch.is_grad_enabled() and bool(training)
-        tokens = BackboneFn.apply(hip, cam, 3, *[im.contiguous().float() for im in imgs], *vit_params)
+        tokens, cls = BackboneFn.apply(hip, cam, 3, *[im.contiguous().float() for im in imgs], *vit_params)
         tok4 = tokens.view(3, B, hip.L, hip.out_dim)
-        return tokens, tok4[:, :, 1:], tok4[:, :, 0]
+        # cls is its own (small) output: the ReID heads' gradient comes back as [3B, 512] instead of a zero-filled token tensor
+        return tokens, tok4[:, :, 1:], cls.view(3, B, hip.out_dim)
 
     def _sim(self, tokens, B, training=True):
         hip = self.hip

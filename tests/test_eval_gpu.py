@@ -116,7 +116,7 @@ def test_do_train_and_do_inference_run_the_reference_loop(dev, tmp_path, caplog)
     optimizer, optimizer_center = make_optimizer(cfg, model, center)        # CPU model: plain torch.optim.Adam
     scheduler = create_scheduler(cfg, optimizer)
     train_loader = SyntheticTriplets(batch=4, hw=tuple(ocfg.size_train), num_instances=2, cams=ocfg.camera_num, steps=3, seed=3)
-    val_loader = ValLoader(ocfg, n=14, bs=5, seed=50)
+    val_loader = ValLoader(ocfg, n=21, bs=6, seed=50)          # 5 queries + 16 gallery (Rank-10 is logged)
     caplog.set_level(logging.INFO)
     do_train(cfg, model, center, train_loader, val_loader, optimizer, optimizer_center, scheduler, loss_fn, 5, 0, cfg.MODEL.stageName)
     text = caplog.text

@@ -341,7 +341,7 @@ def test_train_step_adopts_an_optimizer_built_on_the_cpu_model(dev):
         ts2.step(*batch2)
     torch.cuda.synchronize()
     a, b = model.hip.flat.data, model2.hip.flat.data
-    assert rel_err(a, b) < 1e-5
+    assert rel_err(a, b) < 1e-4          # (not bit-equal: a few bias / LayerNorm gradients are summed with f32 atomics)
     w = "clip_vision_encoder.base.transformer.resblocks.0.mlp.c_fc.weight"
     assert not torch.equal(model.state_dict()[w].cpu(), sd[w])
 
