@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void dot_nn_kernel(const float* __restrict__ A
 
 // ---- label-smoothed CE: loss = sum_b sum_k -t_bk logp_bk / B, t = (1-eps) onehot + eps/C ; dlogits = scale*(p - t)/B ----
 __global__ __launch_bounds__(256) void ce_ls_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int B, int C, float eps,
-                                                    const float* __restrict__ upstream, float weight, float* __restrict__ loss,
+                                                    const float* __restrict__ upstream, float weight, float* __restrict__ row_loss,
                                                     float* __restrict__ dlogits) {
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void ce_ls_kernel(const float* __restrict__ lo
     part = wave_sum(part);
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
-    if (tid == 0) atomicAdd(loss, weight * (red[0] + red[1] + red[2] + red[3]) / B);
+    // per-row term; triplet_mine_kernel adds the rows up in a fixed order (atomics across the B blocks reordered the sum)
+    if (tid == 0) row_loss[b] = weight * (red[0] + red[1] + red[2] + red[3]) / B;
 }
 
 // ---- batch-hard triplet: gram[B,B] = x x^T given; one workgroup ------------------------------------------------
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(128) void triplet_mine_kernel(const float* __restri
     __shared__ float red[2];
     const int a = threadIdx.x;
     float li = 0.f;
+    const float ce_row = a < B ? coef[2 * a] : 0.f;     // ce_ls_kernel's per-row ID-loss term (read before coef is rewritten)
     if (a < B) {
         const float naa = gram[(size_t)a * B + a];
         const int64_t la = labels[a];
@@ -164,23 +166,34 @@ __global__ __launch_bounds__(128) void triplet_mine_kernel(const float* __restri
         coef[2 * a + 1] = -weight * up * g / B / fmaxf(dan, 1e-6f);
         if (dap * dap <= 1e-12f) coef[2 * a] = 0.f;                   // clamp active (self is the hardest positive): zero gradient
     }
-    li = wave_sum(li);
+    li = wave_sum(weight * li / B + ce_row);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = li;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, weight * (red[0] + red[1]) / B);
+    if (threadIdx.x == 0) loss[0] = red[0] + red[1];       // ID + triplet: one store, the same summation tree every run
 }
-// dx[a] += ca (x_a - x_p) + cn (x_a - x_n) ; dx[p] -= ca (x_a - x_p) ; dx[n] -= cn (x_a - x_n)
+// anchor a contributes  dx[a] += ca (x_a - x_p) + cn (x_a - x_n) ; dx[p] -= ca (x_a - x_p) ; dx[n] -= cn (x_a - x_n).
+// Owner computes: block r gathers every anchor's contribution to ROW r in anchor order -- several anchors share a hardest
+// positive / negative, and scattering with atomics made this gradient (which enters the CLS token gradient and with it the
+// whole backbone backward) depend on the order the blocks happened to run in.
 __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ x, const int* __restrict__ pidx, const int* __restrict__ nidx,
                                                           const float* __restrict__ coef, int B, int F, float* __restrict__ dx) {
-    const int a = blockIdx.x;
-    const int p = pidx[a], n = nidx[a];
-    const float ca = coef[2 * a], cn = coef[2 * a + 1];
+    __shared__ int sp[128], sn[128];
+    __shared__ float sca[128], scn[128];
+    const int r = blockIdx.x;
+    for (int a = threadIdx.x; a < B; a += 256) { sp[a] = pidx[a]; sn[a] = nidx[a]; sca[a] = coef[2 * a]; scn[a] = coef[2 * a + 1]; }
+    __syncthreads();
     for (int c = threadIdx.x; c < F; c += 256) {
-        const float xa = x[(size_t)a * F + c];
-        const float gp = ca * (xa - x[(size_t)p * F + c]), gn = cn * (xa - x[(size_t)n * F + c]);
-        atomicAdd(dx + (size_t)a * F + c, gp + gn);
-        atomicAdd(dx + (size_t)p * F + c, -gp);
-        atomicAdd(dx + (size_t)n * F + c, -gn);
+        float acc = 0.f;
+        for (int a = 0; a < B; ++a) {
+            const int p = sp[a], n = sn[a];
+            if (a != r && p != r && n != r) continue;
+            const float xa = x[(size_t)a * F + c];
+            const float gp = sca[a] * (xa - x[(size_t)p * F + c]), gn = scn[a] * (xa - x[(size_t)n * F + c]);
+            if (a == r) acc += gp + gn;
+            if (p == r) acc -= gp;
+            if (n == r) acc -= gn;
+        }
+        dx[(size_t)r * F + c] += acc;
     }
 }
 
@@ -212,8 +225,8 @@ int sig_launch_reid_loss(const float* logits, const float* feat, const int64_t* 
                          float* coef, float* dfeat, hipStream_t st) {
     SIG_CHECK_ARG(logits && feat && target && loss && gram && pidx && nidx && coef, "reid_loss: null pointer");
     SIG_CHECK_ARG(B > 1 && B <= 128 && (F & 3) == 0, "reid_loss: batch %d must be in 2..128", B);
-    (void)hipMemsetAsync(loss, 0, sizeof(float), st);
-    hipLaunchKernelGGL(ce_ls_kernel, dim3(B), dim3(256), 0, st, logits, target, B, C, eps, upstream, w_id, loss, dlogits);
+    // ce_ls parks its per-row loss terms in coef[2a]; triplet_mine (always launched) reads them, then rewrites coef
+    hipLaunchKernelGGL(ce_ls_kernel, dim3(B), dim3(256), 0, st, logits, target, B, C, eps, upstream, w_id, coef, dlogits);
     SIG_CHECK_LAUNCH("ce_ls");
     hipLaunchKernelGGL(dot_nt_kernel, dim3(sig_ceil_div(B * B, 4)), dim3(256), 0, st, feat, feat, B, B, F, gram);
     SIG_CHECK_LAUNCH("gram");

@@ -399,14 +399,21 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 24; ++r) dpr[r] = 0.f;
     }
-    // delta via LDS atomics (24 rows)
-    if (tid < 24) sdelta[tid] = 0.f;
-    __syncthreads();
+    // delta[r] = sum_j p dP: per-wave partials, added in wave order (LDS float atomics made the order, and with it the last
+    // bit of every dS, vary from run to run)
+    __shared__ float spart[24][8];
 #pragma unroll
     for (int r = 0; r < 24; ++r) {
         float v = tid < NK ? sp[r][tid] * dpr[r] : 0.f;
         v = wave_sum(v);
-        if (lane == 0) atomicAdd(&sdelta[r], v);
+        if (lane == 0) spart[r][wave] = v;
+    }
+    __syncthreads();
+    if (tid < 24) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += spart[tid][w];
+        sdelta[tid] = t;
     }
     __syncthreads();
     if (tid < NK) {
@@ -437,7 +444,6 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict_
         dq[((size_t)b * 3 + 1) * SIM_D + c] = a1;
         dq[((size_t)b * 3 + 2) * SIM_D + c] = a2;
     }
-    (void)wave;
 }
 
 int sig_launch_xattn_fwd(const float* q, const bf16_t* kv, int B, int NK, bf16_t* out, float* probs, int dt, hipStream_t st) {

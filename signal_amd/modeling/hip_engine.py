@@ -342,13 +342,16 @@ class HipPath:
         ws["patches"], ws["tok"] = w.z(Mt, K, BF), w.z(Mt, D)
         ws["pre_ln"] = w.z(M, D) if train else None
         ws["emean"], ws["erstd"] = (w.v(M), w.v(M)) if train else (None, None)
-        nx = self.layers + 1 if train else 2
+        # training keeps every block's x_in / x_mid for the LayerNorm backward; inference updates ONE residual stream in place
+        # (out_proj and c_proj read the residual from the buffer they write: 134 -> 118 us for c_proj at B = 64, the output
+        # lines are already in L2 when they are written)
+        nx = self.layers + 1 if train else 1
         ws["x"] = [w.z(M, D) for _ in range(nx)]
         nset = self.layers if train else 1
         acts = []
         for _ in range(nset):
             acts.append(dict(h1=w.z(M, D, BF), mean1=w.v(M), rstd1=w.v(M), qkv=w.z(M, 3 * D, BF), lse=w.v(S * H * L),
-                             attn=w.z(M, D, BF), x_mid=w.z(M, D), h2=w.z(M, D, BF), mean2=w.v(M), rstd2=w.v(M),
+                             attn=w.z(M, D, BF), x_mid=w.z(M, D) if train else ws["x"][0], h2=w.z(M, D, BF), mean2=w.v(M), rstd2=w.v(M),
                              u=w.z(M, Fd, BF) if train else None, g=w.z(M, Fd, BF)))
         ws["acts"] = acts
         ws["hp"], ws["hmean"], ws["hrstd"], ws["tokens"] = w.z(M, D, BF), w.v(M), w.v(M), w.z(M, O)
@@ -357,9 +360,9 @@ class HipPath:
         ws["block_a"] = []
         for i in range(self.layers):
             a = acts[i if train else 0]
-            xin, xout = (ws["x"][i], ws["x"][i + 1]) if train else (ws["x"][i & 1], ws["x"][(i + 1) & 1])
+            xin, xout = (ws["x"][i], ws["x"][i + 1]) if train else (ws["x"][0], ws["x"][0])
             ws["block_a"].append(fill(_lib.SigBlockActs, x_in=xin, x_out=xout, **a))
-        xl = ws["x"][self.layers] if train else ws["x"][self.layers & 1]
+        xl = ws["x"][self.layers] if train else ws["x"][0]
         ws["head_a"] = fill(_lib.SigHeadActs, x=xl, hp=ws["hp"], mean=ws["hmean"], rstd=ws["hrstd"], tokens=ws["tokens"])
         if train:
             ws["du"], ws["dh"], ws["dqkv"] = w.z(M, Fd, BF), w.z(M, D, BF), w.z(M, 3 * D, BF)

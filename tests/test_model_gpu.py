@@ -90,29 +90,36 @@ def test_inference_features_vs_oracle(dev, tag, dtype):
         assert rel_err(feat[same][:, 1536:], ref[same][:, 1536:]) < tol
 
 
-@pytest.mark.parametrize("tag", ["k80", "k112", "k64", "k80_sat"])
-def test_sim_select_bit_exact_vs_reference_fixture(dev, golden, tag):
-    """HIP token selection on the SAME fp32 features as the reference: masks bit-exact on tie-free samples."""
-    from tests.golden.make_golden import head_features
+def hip_sim_select(dev, sd, patches, cls, topk):
+    """sig_sim_select through the C ABI on fp32 features -> (mask int8 [3,B,Lp], raw intra [3,B,Lp], raw inter [B,3,3Lp])."""
     from signal_amd import _lib
     from signal_amd._lib import fill, ref
-    g = golden(f"g2_sim_{tag}")
-    topk = int(g["topk"])
-    ocfg = O.rgbnt201_config(topk=topk)
-    sd = O.init_state_dict(ocfg, seed=int(g["seed_w"]))
-    patches, cls = head_features(ocfg, 8, seed=int(g["seed_x"]), scale=float(g["scale"]))
-    B, Lp, L, d = 8, 128, 129, 512
+    _, B, Lp, d = patches.shape
+    L = Lp + 1
     tokens = torch.cat([cls.unsqueeze(2), patches], dim=2).reshape(3 * B * L, d).contiguous().to(dev)
     z = lambda *s: torch.zeros(*s, device=dev)
     wq, bq = sd["SIM.token_selection.W_q.weight"].to(dev), sd["SIM.token_selection.W_q.bias"].to(dev)
     wk, bk = sd["SIM.token_selection.W_k.weight"].to(dev), sd["SIM.token_selection.W_k.bias"].to(dev)
     bufs = dict(qprime=z(B * 3 * d), cconst=z(B * 3), intra=z(B * 3 * Lp), inter=z(B * 9 * Lp), mask_f=z(3 * B * Lp),
                 mask_u8=torch.zeros(3 * B * Lp, dtype=torch.uint8, device=dev))
-    p = fill(_lib.SigSimParams, sel_wq=wq, sel_bq=bq, sel_wk=wk, sel_bk=bk, topk=topk)
+    p = fill(_lib.SigSimParams, sel_wq=wq, sel_bq=bq, sel_wk=wk, sel_bk=bk, topk=topk, dtype=0)
     a = fill(_lib.SigSimActs, **bufs)
     _lib.call("sig_sim_select", tokens.data_ptr(), B, L, ref(p), ref(a), torch.cuda.current_stream().cuda_stream)
     mask = bufs["mask_u8"].view(3, B, Lp).cpu().numpy().astype(np.int8)
     assert np.array_equal(bufs["mask_f"].view(3, B, Lp).cpu().numpy().astype(np.int8), mask)
+    return mask, bufs["intra"].view(B, 3, Lp).permute(1, 0, 2).cpu(), bufs["inter"].view(B, 3, 3 * Lp).cpu()
+
+
+@pytest.mark.parametrize("tag", ["k80", "k112", "k64", "k80_sat"])
+def test_sim_select_bit_exact_vs_reference_fixture(dev, golden, tag):
+    from tests.golden.make_golden import head_features
+    g = golden(f"g2_sim_{tag}")
+    topk = int(g["topk"])
+    ocfg = O.rgbnt201_config(topk=topk)
+    sd = O.init_state_dict(ocfg, seed=int(g["seed_w"]))
+    patches, cls = head_features(ocfg, 8, seed=int(g["seed_x"]), scale=float(g["scale"]))
+    B, Lp, d = 8, 128, 512
+    mask, intra, _ = hip_sim_select(dev, sd, patches, cls, topk)
     tf = g["tie_free"].astype(bool)
     if tag != "k80_sat":
         assert tf.all()
@@ -121,8 +128,58 @@ def test_sim_select_bit_exact_vs_reference_fixture(dev, golden, tag):
     assert cnt.min() >= min(topk, Lp) and cnt.max() <= Lp
     # raw scores against the oracle's fp32 scores (pre-softmax), to show how much headroom the ranking has
     s_intra = torch.einsum("mbd,mbld->mbl", cls, patches) / np.sqrt(d)
-    got = bufs["intra"].view(B, 3, Lp).permute(1, 0, 2).cpu()
-    assert rel_err(got, s_intra) < 1e-5
+    assert rel_err(intra, s_intra) < 1e-5
+
+
+def _kth_gaps(scores64, k):
+    """per row: (k-th largest) - ((k+1)-th largest) of float64 scores"""
+    s = torch.sort(scores64, dim=-1, descending=True).values
+    return (s[..., k - 1] - s[..., k]).numpy()
+
+
+def test_sim_select_near_tie_sweep_at_b64(dev):
+    """Top-k selection at the metric's batch size over several seeds (6 x 64 samples, 2304 score rows of 128 or 256
+    candidates): HIP masks against the fp32 oracle's, with the k-th gap of every row evaluated in float64.
+
+    The kernel evaluates the inter-modal scores as (W_k^T q).p + q.b_k, the reference as q.(W_k p + b_k) (useA.py:123-128):
+    the same real number, a different fp32 rounding (~1e-6 of the score).  A selection can therefore only differ where the
+    k-th and (k+1)-th scores are closer than that.  Bound asserted here, and documented as the meaning of `tie_free`:
+    ZERO mismatching rows whose float64 gap exceeds EPS = 2e-5 (scores are O(0.1..1)); rows below EPS are reported."""
+    from tests.golden.make_golden import head_features
+    EPS = 2e-5
+    topk, B, Lp, d = 80, 64, 128, 512
+    ocfg = O.rgbnt201_config(topk=topk)
+    rows = mism = mism_above = 0
+    min_gap, worst = np.inf, 0.0
+    for seed in range(6):
+        sd = O.init_state_dict(ocfg, seed=300 + seed)
+        patches, cls = head_features(ocfg, B, seed=400 + seed)
+        mask, intra_h, inter_h = hip_sim_select(dev, sd, patches, cls, topk)
+        ref_mask, _ = O.sim_select(sd, patches, cls, topk)
+        ref_mask = ref_mask.numpy().astype(np.int8)
+        # float64 scores -> gaps of the 3 intra rows (top-80 of 128) and the 3 inter rows (top-160 of the 256 cross-modal ones)
+        p64, c64 = patches.double(), cls.double()
+        s_intra = torch.einsum("mbd,mbld->mbl", c64, p64) / np.sqrt(d)                       # [3,B,Lp]
+        wq, bq = sd["SIM.token_selection.W_q.weight"].double(), sd["SIM.token_selection.W_q.bias"].double()
+        wk, bk = sd["SIM.token_selection.W_k.weight"].double(), sd["SIM.token_selection.W_k.bias"].double()
+        q = c64.transpose(0, 1) @ wq.t() + bq                                                 # [B,3,d]
+        kk = torch.cat([p64[0], p64[1], p64[2]], dim=1) @ wk.t() + bk                         # [B,3Lp,d]
+        s_inter = q @ kk.transpose(1, 2) / np.sqrt(d)                                         # [B,3,3Lp]
+        assert rel_err(intra_h, s_intra) < 1e-5 and rel_err(inter_h, s_inter) < 1e-5
+        gap_i = _kth_gaps(s_intra, topk)                                                      # [3,B]
+        gap_c = np.stack([_kth_gaps(torch.cat([s_inter[:, m, a * Lp:(a + 1) * Lp], s_inter[:, m, b * Lp:(b + 1) * Lp]], dim=1), 2 * topk)
+                          for m, (a, b) in enumerate(O.INTER_OTHERS)])                        # [3,B]
+        sample_gap = np.minimum(gap_i.min(0), gap_c.min(0))                                   # [B]: tightest of a sample's 6 rows
+        bad = (mask != ref_mask).any(axis=(0, 2))                                             # [B]
+        rows += 6 * B
+        mism += int(bad.sum())
+        mism_above += int((bad & (sample_gap > EPS)).sum())
+        min_gap = min(min_gap, float(sample_gap.min()))
+        worst = max(worst, float(sample_gap[bad].max()) if bad.any() else 0.0)
+    print(f"[sim sweep] {rows} score rows at B=64: {mism} samples differ from the fp32 oracle; largest float64 k-th gap among them "
+          f"{worst:.2e}; smallest gap in the sweep {min_gap:.2e}; mismatches above EPS={EPS:g}: {mism_above}")
+    assert mism_above == 0
+    assert mism <= 2            # near-ties below EPS are rare on continuous data
 
 
 def test_device_prefetcher_feeds_identical_batches(dev):

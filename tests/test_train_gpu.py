@@ -410,3 +410,29 @@ def test_fp16_and_bf16_engines_take_the_same_first_step(dev):
     a, b = res["bf16"], res["fp16"]
     live = (a != 0) | (b != 0)
     assert cos(a[live], b[live]) > 0.97
+
+
+def test_backward_is_reproducible_run_to_run(dev):
+    """Two independent runs of the same train step (same weights, same batch).  Every kernel on the TOKEN-gradient path is
+    order-deterministic (owner-computes / fixed-order reductions instead of float atomics), so the backward signal that the
+    16-bit roundings see is bit-identical and so is every large weight gradient (256x256 TN kernel: per-chunk partial tiles
+    + a fixed-order reduce).  What is still summed with f32 atomics -- bias / LayerNorm / embedding gradients and the small
+    weight gradients of the 128x128 TN kernel -- may differ in the last bits only (round 1: 1-3e-3 of the whole gradient,
+    because the scatter order fed back into the 16-bit backward signal)."""
+    from signal_amd.engine.trainer import TrainStep
+    grads, losses = [], []
+    for _ in range(2):
+        ocfg, sd, cfg, model, _, batch = _small_train_setup(dev, seed=77)
+        cfg.SOLVER.BASE_LR = 0.0
+        ts = TrainStep(cfg, model, num_classes=ocfg.num_classes)
+        losses.append(ts.step(*batch).item())
+        torch.cuda.synchronize()
+        grads.append(model.hip.flat.grad.clone())
+        fl = model.hip.flat
+    assert losses[0] == losses[1]                                  # forward + loss: bit-identical
+    a, b = grads
+    assert rel_err(a, b) < 2e-6
+    big = [n for n in fl.names if n.endswith(("in_proj_weight", "out_proj.weight", "c_fc.weight", "c_proj.weight")) and "resblocks" in n]
+    assert len(big) == 48
+    for n in big:
+        assert torch.equal(fl.view(a, n), fl.view(b, n)), n

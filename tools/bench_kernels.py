@@ -29,6 +29,11 @@ for name, n, k, epi in [("qkv", 2304, 768, ops.BIAS_BF16), ("out_proj", 768, 768
     aux = torch.zeros(Mp, n, device=dev, dtype=torch.bfloat16) if epi == ops.BIAS_GELU_BF16 else None
     ms = timeit(lambda: ops.gemm_nt(a, w, M, epi, out, bias=bias, res=out if f32 else None, aux=aux))
     res["nt_" + name] = dict(ms=round(ms, 4), tflops=round(2 * M * n * k / ms / 1e9, 1))
+    if f32:     # as in the model: the residual comes from ANOTHER buffer (x_in -> x_mid -> x_out), not in place
+        r2 = torch.randn(Mp, n, device=dev)
+        ms = timeit(lambda: ops.gemm_nt(a, w, M, epi, out, bias=bias, res=r2))
+        res["nt_" + name + "_sep"] = dict(ms=round(ms, 4), tflops=round(2 * M * n * k / ms / 1e9, 1))
+        del r2
     # wgrad of the same layer: dW[n,k] = dY^T X
     dy = torch.randn(Mp, n, device=dev).to(torch.bfloat16); dy[M:] = 0
     dw = torch.zeros(n, k, device=dev)
