@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ce_ls_kernel(const float* __restrict__ lo
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
     // per-row term; triplet_mine_kernel adds the rows up in a fixed order (atomics across the B blocks reordered the sum)
-    if (tid == 0) row_loss[b] = weight * (red[0] + red[1] + red[2] + red[3]) / B;
+    if (tid == 0) row_loss[2 * b] = weight * (red[0] + red[1] + red[2] + red[3]) / B;   // (coef[2a]: the slot triplet_mine rewrites last)
 }
 
 // ---- batch-hard triplet: gram[B,B] = x x^T given; one workgroup ------------------------------------------------
