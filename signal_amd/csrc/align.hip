@@ -330,6 +330,9 @@ __global__ __launch_bounds__(512) void lam_tail_fwd_kernel(const float* __restri
 }
 
 // loss = (MSE(n,r) + MSE(t,r) + MSE(t,n)) / 3 over B*512*P elements (useB.py:161-165); samp = [3][B*P*512]
+// Deterministic two-stage sum (atomics across blocks reordered it): LAM_LOSS_BLOCKS blocks park their partial sums behind
+// loss[0] (the buffer holds 1 + LAM_LOSS_BLOCKS floats), then ONE thread-block adds them in block order.
+#define LAM_LOSS_BLOCKS 64
 __global__ __launch_bounds__(256) void lam_loss_kernel(const float* __restrict__ samp, size_t n, float* __restrict__ loss) {
     __shared__ float red[4];
     float acc = 0.f;
@@ -340,8 +343,12 @@ __global__ __launch_bounds__(256) void lam_loss_kernel(const float* __restrict__
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    // ONE block (launcher): a plain store, the same summation tree every run (atomics across blocks reordered the sum)
-    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (3.0f * (float)n);
+    if (threadIdx.x == 0) loss[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void lam_loss_final_kernel(float* __restrict__ loss, size_t n) {
+    float v = loss[1 + threadIdx.x];                         // LAM_LOSS_BLOCKS == 64 partials, fixed shuffle tree
+    v = wave_sum(v);
+    if (threadIdx.x == 0) loss[0] = v / (3.0f * (float)n);
 }
 
 // backward of the tail for one (sample, modality).  Writes da1pre bf16 [B*Lp,512] (gradient of the conv_offset.0
@@ -494,7 +501,10 @@ int sig_launch_lam_tail_fwd(const float* tokens, int m, int B, int L, int h, int
 }
 int sig_launch_lam_loss(const float* samp, size_t n, float* loss, hipStream_t st) {
     SIG_CHECK_ARG(samp && loss && n > 0, "lam_loss: bad arguments");
-    hipLaunchKernelGGL(lam_loss_kernel, dim3(1), dim3(256), 0, st, samp, n, loss);     // n = B * P * 512 <= 0.5 M elements
+    static_assert(LAM_LOSS_BLOCKS == 64, "lam_loss_final_kernel sums exactly one wave of partials");
+    hipLaunchKernelGGL(lam_loss_kernel, dim3(LAM_LOSS_BLOCKS), dim3(256), 0, st, samp, n, loss);
+    SIG_CHECK_LAUNCH("lam_loss");
+    hipLaunchKernelGGL(lam_loss_final_kernel, dim3(1), dim3(64), 0, st, loss, n);
     SIG_CHECK_LAUNCH("lam_loss");
     return 0;
 }

@@ -57,14 +57,16 @@ __device__ __forceinline__ float gelu_erf_grad_f(float u) {
 // sc1 stores are write-through and DROP the line (MI355X_MICROARCH.md, stores of each flavour).
 // Measured per epilogue at M = 24768 (tools/ab_kernels.sh, same box, plain / sc1 / nt in us): qkv (bias, 16-bit out)
 // 96.5 / 94.0 / 100; c_fc 148 / 141-152 / 151; GELU' dgrad 152 / 160 / 139; f32 + residual outputs 50.5 / 66 / 51 and
-// 118 / 133 / 120 (sc1 doubles WRITE_SIZE there: the residual lines are read and rewritten).  So: sc1 for the plain
-// 16-bit projection outputs, nt for the GELU' dgrad, default for everything else.  L2-miss traffic of c_fc moved only
+// 118 / 133 / 120 (sc1 doubles WRITE_SIZE there: the residual lines are read and rewritten).  In the model (tools/
+// ab_profile.sh, train step) qkv keeps its gain (13.5 -> 13.3 ms per 144 launches) but the GELU' dgrad LOSES with nt (25.5
+// -> 26.4: its saved pre-activations come from HBM there, not from the Infinity Cache as in the micro-benchmark loop).
+// So: sc1 for the plain 16-bit projection outputs, default for everything else.  L2-miss traffic of c_fc moved only
 // 187 -> 156 MB: the operand re-fetches come from sibling blocks drifting apart in time, not from output pollution, and
 // are served by the 256 MB Infinity Cache (A + W = 43 MB).
 #ifdef SIG_STORE_AUX
 template <int EPI> constexpr int store_aux() { return SIG_STORE_AUX; }      // A/B builds: one policy everywhere
 #else
-template <int EPI> constexpr int store_aux() { return EPI == SIG_EPI_BIAS_BF16 ? 16 : (EPI == SIG_EPI_DGELU_BF16 ? 2 : 0); }
+template <int EPI> constexpr int store_aux() { return EPI == SIG_EPI_BIAS_BF16 ? 16 : 0; }
 #endif
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(void* base) {

@@ -496,7 +496,7 @@ class HipPath:
             w = _Ws(self.flat.device)
             Rp = pad_rows(R)
             t = dict(xb=w.z(3 * Rp, 512, BF), q=w.z(3 * Rp, 512, BF), a1=w.z(3 * Rp, 512, BF), a1pre=w.z(3 * Rp, 512, BF),
-                     a2pre=w.v(3 * B * P * 512), offs=w.v(3 * B * P * 3), samp=w.v(3 * B * P * 512), loss=w.v(1))
+                     a2pre=w.v(3 * B * P * 512), offs=w.v(3 * B * P * 3), samp=w.v(3 * B * P * 512), loss=w.v(1 + 64))
             ws = {"B": B, "train": train, "t": t, "acts": fill(_lib.SigLamActs, **t)}
             if train:
                 s = dict(da1pre=w.z(R, 512, BF), dq=w.z(R, 512, BF), dx=w.z(R, 512))
