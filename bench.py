@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_TFLOPS = 2500.0   # MI355X dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
-PROF_TN256 = 100            # sig_prof_begin class id: gemm_tn256_kernel (weight gradients), any shape
+PROF_TN256 = 100            # sig_prof_begin class id: the 256x256 weight-gradient kernel (gemm_tn256x16_kernel), any shape
 
 
 def parse():
@@ -231,8 +231,8 @@ def main():
             parallelism = parallelism.replace("RCCL", args.backend + " (test backend)")
         # dominant kernel of the train step by total time (profiles/r02_train_*): the weight-gradient GEMM
         prof = (PROF_TN256, 0, 0)
-        kname = "gemm_tn256_kernel (weight gradients dW = dY^T X of qkv / out_proj / c_fc / c_proj, M=%d rows)" % M
-        kkey = "gemm_tn256_kernel"
+        kname = "gemm_tn256x16_kernel (weight gradients dW = dY^T X of qkv / out_proj / c_fc / c_proj, M=%d rows)" % M
+        kkey = "gemm_tn256x16_kernel"
     else:
         step = fwd_step
         parallelism = f"dp{world} (independent shards, no collective)"

@@ -620,6 +620,11 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     bool big = can256 && (mp >> 8) * (p.N >> 8) >= 512;
     if (force == 128) big = false;
     if (force == 256) big = can256;
+    if (EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_BIAS_GELU_BF16) {      // A/B knob: SIG_GEMM_TILE_GELU=128 moves only the GELU epilogues
+        static int force_g = -1;
+        if (force_g < 0) { const char* e = getenv("SIG_GEMM_TILE_GELU"); force_g = e ? atoi(e) : 0; }
+        if (force_g == 128) big = false;
+    }
     const bool timed = g_prof.on && g_prof.epi == EPI && g_prof.N == p.N && g_prof.K == p.K && g_prof.used + 2 <= g_prof.ev.size();
     if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
     if (big) {
@@ -978,6 +983,210 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(SigGemmTN p) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN 256x256, second form: MFMA 16x16x32 instead of 32x32x16.  Same tile, waves, LDS-DMA schedule and phase structure as
+// gemm_tn256_kernel; per wave 8 x 4 accumulator tiles of 16x16 (the same 128 registers).  Why: on LDS-fed bf16 loops the
+// chip holds a higher clock on the 16x16x32 shape at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7:
+// 1.12-1.14x), and the 32x32 shape was chosen only for its atomics-friendly accumulator layout, which the partial-tile
+// flush no longer needs.  A K-step (64 rows of m) = 2 chunks of 32 rows; each chunk is two phases (P column tiles 0-3 /
+// 4-7 against the chunk's 4 Q tiles).  Fragments: lane (col = l & 15, k-group G = l >> 4) holds 8 consecutive m of one
+// column = two ds_read_b64_tr_b16 (rows +0..3, +4..7).  LDS image as before but with the XOR extended by row bit 3:
+//   physical chunk = chunk ^ (((row & 3) << 2) | (((row >> 3) & 1) << 1))
+// -- the two k-groups of a half-wave (rows r, r + 8) read the SAME 16 columns here, and the extra bit moves them to the two
+// halves of each 64-B quarter of the bank row (tools/lds_bank_sim.py: conflict-free).
+// The block's partial tile is stored in FRAGMENT order (one coalesced 1-KB store per MFMA tile and wave); tn_reduce16_kernel
+// un-permutes while it adds the row chunks.
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(512, 2) void gemm_tn256x16_kernel(SigGemmTN p) {
+    constexpr int ROWB = 512, OPB = 64 * ROWB, STAGE = 2 * OPB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tj = p.J >> 8, ti = p.I >> 8, tiles = ti * tj;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id / tiles, t = id - split * tiles;
+    const int tile_i = t / tj, tile_j = t - tile_i * tj;
+    const int i0 = tile_i << 8, j0 = tile_j << 8;
+    const int mbeg = split * p.m_chunk;
+    int mend = mbeg + p.m_chunk;
+    if (mend > p.Mr) mend = p.Mr;
+    const int nk = (mend - mbeg) >> 6;
+    if (nk <= 0) return;
+
+    unsigned po[4], qo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 2 + (lane >> 5);
+        const int c = (lane & 31) ^ (((r & 3) << 2) | (((r >> 3) & 1) << 1));
+        po[j] = (unsigned)(r * p.ldp + c * 8) * 2u;
+        qo[j] = (unsigned)(r * p.ldq + c * 8) * 2u;
+    }
+    const bf16_t* pbase = p.P + (size_t)mbeg * p.ldp + i0;
+    const bf16_t* qbase = p.Q + (size_t)mbeg * p.ldq + j0;
+    const size_t pstep = (size_t)64 * p.ldp, qstep = (size_t)64 * p.ldq;
+    auto dma_p = [&](int j, int kt, int stage) { glds16_untracked_s(pbase + kt * pstep, po[j], smem + stage * STAGE + (wave * 4 + j) * 1024); };
+    auto dma_q = [&](int j, int kt, int stage) { glds16_untracked_s(qbase + kt * qstep, qo[j], smem + stage * STAGE + OPB + (wave * 4 + j) * 1024); };
+
+    // transposed-read addressing: lane = 16*G + 4*tq + pp addresses row (8G + tq), columns 4pp.. of a 16-column tile and
+    // receives column (4tq + pp) = lane & 15, rows 8G .. 8G+3 (+4 for the second read)
+    const int G = lane >> 4, tq = (lane >> 2) & 3, pp = lane & 3;
+    const int wi = (wave >> 2) * 128, wj = (wave & 3) * 64;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int swz = (tq << 2) | ((G & 1) << 1);
+    unsigned fp[8], fq[4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        fp[a] = lds0 + (8 * G + tq) * ROWB + (((((wi >> 3) + 2 * a + (pp >> 1)) ^ swz)) << 4) + ((pp & 1) << 3);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        fq[b] = lds0 + OPB + (8 * G + tq) * ROWB + (((((wj >> 3) + 2 * b + (pp >> 1)) ^ swz)) << 4) + ((pp & 1) << 3);
+    struct Frag4 { bf16x4_t lo[4], hi[4]; };
+    Frag4 pX, pY, qX, qY;
+    auto rd_p = [&](int stage, auto c_c, auto h_c, Frag4& f) {
+        constexpr int C = decltype(c_c)::value, H = decltype(h_c)::value;
+        const unsigned so = stage * STAGE;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const unsigned ad = fp[H * 4 + a] + so;
+            SIG_RDTR(f.lo[a], ad, C * 32 * ROWB);
+            SIG_RDTR(f.hi[a], ad, C * 32 * ROWB + 4 * ROWB);
+        }
+    };
+    auto rd_q = [&](int stage, auto c_c, Frag4& f) {
+        constexpr int C = decltype(c_c)::value;
+        const unsigned so = stage * STAGE;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned ad = fq[b] + so;
+            SIG_RDTR(f.lo[b], ad, C * 32 * ROWB);
+            SIG_RDTR(f.hi[b], ad, C * 32 * ROWB + 4 * ROWB);
+        }
+    };
+#define SIG_WAITF4(n, f)                                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                                \
+                 : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]), "+v"(f.lo[3]), "+v"(f.hi[3]))
+#define SIG_WAITF8(n, f, g)                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                                \
+                 : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]), "+v"(f.lo[3]), "+v"(f.hi[3]), \
+                   "+v"(g.lo[0]), "+v"(g.hi[0]), "+v"(g.lo[1]), "+v"(g.hi[1]), "+v"(g.lo[2]), "+v"(g.hi[2]), "+v"(g.lo[3]), "+v"(g.hi[3]))
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // rows [r0, r1) of the 4 x 4 tile block `half` : D[i][j] += sum_m P[m][i] Q[m][j]   (A operand = P fragment, B = Q)
+    auto mma = [&](int half, const Frag4& pf, const Frag4& qf, auto lo_c, auto hi_c) {
+        constexpr int A0 = decltype(lo_c)::value, A1 = decltype(hi_c)::value;
+#pragma unroll
+        for (int a = A0; a < A1; ++a) {
+            const bf16x8_t pa = __builtin_shufflevector(pf.lo[a], pf.hi[a], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bf16x8_t qb = __builtin_shufflevector(qf.lo[b], qf.hi[b], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[half * 4 + a][b] = mfma16<DT>(pa, qb, acc[half * 4 + a][b]);
+            }
+        }
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using C4 = std::integral_constant<int, 4>;
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dma_p(j, 0, 0); dma_q(j, 0, 0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rd_p(0, C0{}, C0{}, pX);
+    rd_q(0, C0{}, qX);
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_p(j, 1, 1);
+    }
+    auto step = [&](int kt, auto more_c, auto more2_c) {
+        constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+        const int st = kt & 1;
+        // P0: pX, qX (16 reads) in flight; pY behind them
+        rd_p(st, C0{}, C1{}, pY);
+        if (MORE) { dma_q(0, kt + 1, st ^ 1); dma_q(1, kt + 1, st ^ 1); dma_q(2, kt + 1, st ^ 1); dma_q(3, kt + 1, st ^ 1); }
+        SIG_WAITF8(8, pX, qX);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, pX, qX, C0{}, C4{});
+        __builtin_amdgcn_sched_barrier(0);
+        // P1: pY landed long ago; next chunk's P half behind it, its Q tiles issued half-way through the MFMAs (lgkmcnt is a
+        // 4-bit counter: never more than 16 reads requested at once)
+        rd_p(st, C1{}, C0{}, pX);
+        SIG_WAITF4(8, pY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, pY, qX, C0{}, C2{});
+        __builtin_amdgcn_sched_barrier(0);
+        rd_q(st, C1{}, qY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, pY, qX, C2{}, C4{});
+        __builtin_amdgcn_sched_barrier(0);
+        // P2: outstanding pX, qY, then pY
+        rd_p(st, C1{}, C1{}, pY);
+        SIG_WAITF8(8, pX, qY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, pX, qY, C0{}, C4{});
+        __builtin_amdgcn_sched_barrier(0);
+        // stage boundary
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(pY.lo[0]), "+v"(pY.hi[0]), "+v"(pY.lo[1]), "+v"(pY.hi[1]), "+v"(pY.lo[2]), "+v"(pY.hi[2]), "+v"(pY.lo[3]),
+                       "+v"(pY.hi[3])::"memory");
+        __builtin_amdgcn_s_barrier();
+        // P3
+        if (MORE) {
+            rd_p(st ^ 1, C0{}, C0{}, pX);
+            rd_q(st ^ 1, C0{}, qX);
+        }
+        if (MORE2) { dma_p(0, kt + 2, st); dma_p(1, kt + 2, st); dma_p(2, kt + 2, st); dma_p(3, kt + 2, st); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, pY, qY, C0{}, C4{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    for (int kt = 0; kt < nk - 2; ++kt) step(kt, T_{}, T_{});
+    if (nk >= 2) step(nk - 2, T_{}, F_{});
+    step(nk - 1, F_{}, F_{});
+
+    // D: col (j) = lane & 15, row (i) = (lane >> 4) * 4 + reg
+    if (p.ws) {
+        f32x4_t* wt = (f32x4_t*)(p.ws + (size_t)id * 65536) + (size_t)wave * 32 * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wt[(a * 4 + b) * 64] = acc[a][b];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    atomicAdd(p.out + (size_t)(i0 + wi + a * 16 + (lane >> 4) * 4 + e) * p.ldo + j0 + wj + b * 16 + (lane & 15), acc[a][b][e]);
+    }
+}
+
+// out += sum over row chunks of the FRAGMENT-order partial tiles of gemm_tn256x16_kernel: float4 q of a tile = (wave, a, b, lane)
+// holds rows i = wi + 16a + 4(lane >> 4) .. +3 of column j = wj + 16b + (lane & 15)
+__global__ __launch_bounds__(256) void tn_reduce16_kernel(const float* __restrict__ ws, float* __restrict__ out, int I, int J, int ldo,
+                                                          int tiles, int split) {
+    const int tj = J >> 8;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index over all tiles
+    if (q >= (size_t)tiles * 16384) return;
+    const int t = (int)(q >> 14), r = (int)(q & 16383);
+    const int lane = r & 63, f = r >> 6, wave = f >> 5, a = (f >> 2) & 7, b = f & 3;
+    const f32x4_t* src = (const f32x4_t*)(ws + (size_t)t * 65536) + r;
+    f32x4_t acc = *src;
+    for (int s = 1; s < split; ++s) acc += src[(size_t)s * tiles * 16384];
+    const int i = (t / tj) * 256 + (wave >> 2) * 128 + a * 16 + (lane >> 4) * 4;
+    const int j = (t % tj) * 256 + (wave & 3) * 64 + b * 16 + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[(size_t)(i + e) * ldo + j] += acc[e];
+}
+
 // out[i][j] += sum over row chunks of the partial tiles written by gemm_tn256_kernel (unit = split * tiles + tile)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int I, int J, int ldo,
                                                         int tiles, int split) {
@@ -1050,6 +1259,7 @@ static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {
         static bool attr256 = false;
         if (!attr256) {
             (void)hipFuncSetAttribute((const void*)&gemm_tn256_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute((const void*)&gemm_tn256x16_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             attr256 = true;
         }
         const int tiles = (p.I >> 8) * (p.J >> 8);
@@ -1065,15 +1275,21 @@ static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {
         // bench.py's roofline leg: class SIG_PROF_TN256 times every launch of this kernel (N/K = 0) or one (I, J) shape
         const bool timed = g_prof.on && g_prof.epi == SIG_PROF_TN256 && (g_prof.N == 0 || (g_prof.N == p.I && g_prof.K == p.J)) &&
                            g_prof.used + 2 <= g_prof.ev.size();
+        static int shape = -1;      // SIG_TN256_SHAPE=32: the 32x32x16 form (A/B); default: 16x16x32
+        if (shape < 0) { const char* e = getenv("SIG_TN256_SHAPE"); shape = e ? atoi(e) : 16; }
         if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-        hipLaunchKernelGGL(gemm_tn256_kernel<DT>, dim3(tiles * split), dim3(512), 131072, st, p);
+        if (shape == 32) hipLaunchKernelGGL(gemm_tn256_kernel<DT>, dim3(tiles * split), dim3(512), 131072, st, p);
+        else hipLaunchKernelGGL(gemm_tn256x16_kernel<DT>, dim3(tiles * split), dim3(512), 131072, st, p);
         if (timed) {
             (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
             g_prof.used += 2;
             g_prof.flops += 2.0 * p.Mr * p.I * p.J;
         }
         SIG_CHECK_LAUNCH("gemm_tn256");
-        if (p.ws) {
+        if (p.ws && shape != 32) {
+            hipLaunchKernelGGL(tn_reduce16_kernel, dim3(tiles * 64), dim3(256), 0, st, p.ws, p.out, p.I, p.J, p.ldo, tiles, split);
+            SIG_CHECK_LAUNCH("tn_reduce16");
+        } else if (p.ws) {
             hipLaunchKernelGGL(tn_reduce_kernel, dim3(sig_ceil_div(p.I * (p.J >> 2), 256)), dim3(256), 0, st, p.ws, p.out, p.I, p.J, p.ldo,
                                tiles, split);
             SIG_CHECK_LAUNCH("tn_reduce");

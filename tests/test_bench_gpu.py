@@ -33,7 +33,7 @@ def test_bench_default_is_the_train_step_with_the_json_contract():
     assert d["config"]["workload"].startswith("configs[2]") and "model" not in d["config"]
     assert abs(d["value"] - 64 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.02
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and "gemm_tn256" in r["kernel"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and "gemm_tn256x16" in r["kernel"]
     assert r["launches"] > 0 and r["launches"] % 3 == 0 and 0.05 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or r["traffic"] > 1e8
     f = d["fwd_sim"]
