@@ -493,6 +493,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
 #ifdef SIG_GEMM_STAMPS
     SIG_STAMP(ts1);
 #endif
+#ifdef SIG_NT256_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the second-dispatched half (MI355X_MICROARCH, two waves per SIMD, item 4)
+#endif
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
     rd_a(0, 0, H0{}, aX);
@@ -601,6 +604,9 @@ int sig_prof_end_impl(double* total_ms, int* launches, double* flops) {
 
 
 static int choose_band(int tn, int K, int BN) {
+    static int force = -1;       // SIG_GEMM_BAND=<column tiles per band> (A/B knob; must divide the tile count)
+    if (force < 0) { const char* e = getenv("SIG_GEMM_BAND"); force = e ? atoi(e) : 0; }
+    if (force > 0 && tn % force == 0) return force;
     int wmax = (int)(2400000LL / (2LL * BN * K));
     if (wmax < 1) wmax = 1;
     for (int nb = 1; nb <= tn; ++nb)

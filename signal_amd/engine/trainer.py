@@ -12,7 +12,7 @@ import torch
 
 from .. import _lib
 from ..layers.make_loss import make_loss, total_loss
-from ..parallel.reducer import GradReducer, plan_buckets
+from ..parallel.reducer import GradReducer, plan_buckets, split_rest
 from ..solver.make_optimizer import FusedAdam, gradless, make_optimizer
 
 
@@ -78,11 +78,13 @@ class TrainStep:
         if world_size > 1:
             fl = hip.flat
             sizes = {n: fl.byname[n].numel() for n in fl.names}
-            blocks, rest = plan_buckets(fl.names, fl.offsets, sizes, fl.total, skip=self.inactive)
-            self.reducer = GradReducer(fl.grad, blocks, rest)
+            blocks, _ = plan_buckets(fl.names, fl.offsets, sizes, fl.total, skip=self.inactive)
+            early, late = split_rest(fl.names, fl.offsets, sizes, skip=self.inactive)
+            self.reducer = GradReducer(fl.grad, blocks, late, rest_early=early)
             self.reducer.broadcast_params(fl.data)      # DDP's construction-time broadcast from rank 0
             hip._pack()
             hip.on_block_grads_ready = self.reducer.on_block_ready
+            hip.on_head_grads_ready = self.reducer.on_head_ready
             if self.fused:
                 self.optimizer.grad_scale = 1.0 / world_size
         model.train()

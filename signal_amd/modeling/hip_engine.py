@@ -409,6 +409,8 @@ class HipPath:
         _lib.call("sig_head_bwd", d, ref(self.head_p), ref(ws["head_a"]), ref(self.head_g), ws["dtokens"].data_ptr(),
                   ws["dtok_b"].data_ptr(), ws["dh"].data_ptr(), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(),
                   self.b_proj_grad[self.layers - 1].data_ptr(), st)
+        if self.on_head_grads_ready is not None:     # every head-side gradient (heads ran before this backward) is final now
+            self.on_head_grads_ready()
         for i in reversed(range(self.layers)):
             below = self.b_proj_grad[i - 1].data_ptr() if i > 0 else None   # column sums of dx_in = block i-1's c_proj bias grad
             _lib.call("sig_block_bwd", d, ref(self.block_p[i]), ref(ws["block_a"][i]), ref(self.block_g[i]),
@@ -420,7 +422,8 @@ class HipPath:
         _lib.call("sig_embed_bwd", d, ref(self.embed_p), ref(ws["embed_a"]), ref(self.embed_g), ws["dx"].data_ptr(),
                   ws["dpre"].data_ptr(), ws["dtok_e"].data_ptr(), None if cam is None else cam.data_ptr(), self.patch, st)
 
-    on_block_grads_ready = None  # hook for the data-parallel reducer (signal_amd/parallel)
+    on_block_grads_ready = None  # hooks for the data-parallel reducer (signal_amd/parallel)
+    on_head_grads_ready = None
 
     # The token tensor handed out by a TRAINING forward and the buffer that collects its gradient.  SIM / GAM / LAM
     # backward accumulate straight into that buffer when their input IS this tensor (they return no gradient to autograd),

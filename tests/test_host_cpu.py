@@ -166,6 +166,16 @@ def test_bucket_plan_covers_the_flat_buffer():
     assert covered + skipped == off
     spans = sorted(list(blocks.values()) + rest)
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "buckets must not overlap"
+    # the remainder splits into what is final when the ViT backward starts (reduced under the 12 blocks) and the embedding group
+    from signal_amd.parallel.reducer import split_rest
+    early, late = split_rest(names, offsets, sizes, skip=skip)
+    assert sum(hi - lo for lo, hi in early) + sum(hi - lo for lo, hi in late) == sum(hi - lo for lo, hi in rest)
+    late_names = {n for n in names if any(lo <= offsets[n] < hi for lo, hi in late)}
+    assert late_names == {"clip_vision_encoder.cv_embed", "clip_vision_encoder.base.class_embedding", "clip_vision_encoder.base.positional_embedding",
+                          "clip_vision_encoder.base.conv1.weight", "clip_vision_encoder.base.ln_pre.weight", "clip_vision_encoder.base.ln_pre.bias"}
+    assert sum(hi - lo for lo, hi in late) < 1.0e6 < sum(hi - lo for lo, hi in early)      # ~0.8 M late, ~5 M early elements
+    both = sorted(early + late)
+    assert all(a[1] <= b[0] for a, b in zip(both, both[1:]))
 
 
 _WORKER = r'''
@@ -177,11 +187,12 @@ dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], ra
 n = 4096
 g = torch.arange(n, dtype=torch.float32) * (rank + 1)
 blocks = {0: (256, 1024), 1: (1024, 1792)}
-rest = [(0, 256), (2048, 4096)]            # [1792, 2048) plays the grad-less range: never reduced
-red = GradReducer(g, blocks, rest)
+rest = [(0, 256)]                          # [1792, 2048) plays the grad-less range: never reduced
+red = GradReducer(g, blocks, rest, rest_early=[(2048, 4096)])
 p = torch.full((16,), float(rank))
 red.broadcast_params(p)
 assert torch.equal(p, torch.zeros(16))
+red.on_head_ready(); assert len(red.pending) == 1
 red.on_block_ready(1); red.on_block_ready(0)   # backward order
 red.finish()
 want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
