@@ -44,6 +44,9 @@ def parse():
                     help="MFMA operand type (fp32 accumulate, residual stream, LayerNorm and softmax either way); "
                          "fp16 trains with dynamic loss scaling like the reference's AMP GradScaler")
     ap.add_argument("--batch", type=int, default=64, help="triplets per GPU (metric is quoted at 64)")
+    ap.add_argument("--config", default="rgbnt201", choices=["rgbnt201", "rgbnt100", "msvr310"],
+                    help="which shipped Signal.yml to run (the metric is quoted on rgbnt201; rgbnt100 = BASELINE configs[4]'s "
+                         "geometry: 128x256 images, TOPK 112, three per-modality heads, 16 instances per identity)")
     ap.add_argument("--backend", default=os.environ.get("SIGNAL_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (tests only: RCCL needs a device per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -66,25 +69,29 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def build_model(dev, dtype):
+CONFIGS = {"rgbnt201": ("RGBNT201", 171, 4), "rgbnt100": ("RGBNT100", 50, 8), "msvr310": ("MSVR310", 155, 8)}   # yml dir, classes, cameras
+
+
+def build_model(dev, dtype, config="rgbnt201"):
     from signal_amd.config import get_cfg_defaults
     from signal_amd.modeling import make_frame
+    name, ncls, ncam = CONFIGS[config]
     cfg = get_cfg_defaults()
-    cfg.merge_from_file(os.path.join(ROOT, "configs", "RGBNT201", "Signal.yml"))
+    cfg.merge_from_file(os.path.join(ROOT, "configs", name, "Signal.yml"))
     cfg.MODEL.OPERAND_DTYPE = dtype
     cfg.freeze()
     torch.manual_seed(1234)
-    model = make_frame(cfg, num_class=171, camera_num=4, view_num=0).to(dev)
+    model = make_frame(cfg, num_class=ncls, camera_num=ncam, view_num=0).to(dev)
     return cfg, model
 
 
-def synthetic(cfg, B, dev, seed):
+def synthetic(cfg, B, dev, seed, ncam=4):
     g = torch.Generator(device="cpu").manual_seed(seed)
     H, W = cfg.INPUT.SIZE_TRAIN
     img = {m: torch.randn(B, 3, H, W, generator=g).to(dev) for m in ("RGB", "NI", "TI")}
     k = cfg.DATALOADER.NUM_INSTANCE
     vid = (torch.arange(B) // k).to(dev)
-    cam = torch.randint(0, 4, (B,), generator=g).to(dev)
+    cam = torch.randint(0, ncam, (B,), generator=g).to(dev)
     return img, vid, cam
 
 
@@ -177,9 +184,13 @@ def main():
             dist.init_process_group("gloo")
     from signal_amd import _lib, ops
 
-    cfg, model = build_model(dev, args.dtype)
+    cfg, model = build_model(dev, args.dtype, args.config)
     B = args.batch
-    img, vid, cam = synthetic(cfg, B, dev, 1234 + rank)
+    ncls, ncam = CONFIGS[args.config][1:]
+    if B % cfg.DATALOADER.NUM_INSTANCE or B // cfg.DATALOADER.NUM_INSTANCE < 2:
+        raise SystemExit(f"--batch {B}: need at least two identities of {cfg.DATALOADER.NUM_INSTANCE} instances (batch-hard triplet mining)")
+    img, vid, cam = synthetic(cfg, B, dev, 1234 + rank, ncam)
+    cfg_tag = CONFIGS[args.config][0] + " %dx%d" % tuple(cfg.INPUT.SIZE_TRAIN)
     D, Fd, L = model.hip.D, model.hip.F, model.hip.L
     M = 3 * B * L
 
@@ -221,7 +232,7 @@ def main():
     ts = None
     if args.workload == "train":
         from signal_amd.engine.trainer import TrainStep
-        ts = TrainStep(cfg, model, num_classes=171, world_size=world)
+        ts = TrainStep(cfg, model, num_classes=ncls, world_size=world)
 
         def step():
             return ts.step(img, vid, cam)
@@ -265,9 +276,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": {"fwd_sim": "configs[1]: three-stream ViT-B/16 forward + SIM, RGBNT201 256x128, random init",
-                                "train": "configs[%d]: full Signal (SIM+GAM+LAM) train step incl. fused Adam, RGBNT201 256x128, random init"
-                                % (2 if world == 1 else 3)}[args.workload],
+        "config": {"workload": {"fwd_sim": "configs[1]: three-stream ViT-B/16 forward + SIM, %s, random init" % cfg_tag,
+                                "train": "configs[%d]: full Signal (SIM+GAM+LAM) train step incl. fused Adam, %s, random init"
+                                % (2 if world == 1 else 3, cfg_tag)}[args.workload],
                    "batch_per_gpu": B, "global_batch": B * world, "tokens_per_image": 129, "parallelism": parallelism},
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,

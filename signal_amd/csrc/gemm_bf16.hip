@@ -88,8 +88,14 @@ __device__ __forceinline__ void lane_swap16(uint32_t& a, uint32_t& b) {
     b = r[1];
 }
 
-template <int EPI, int TM, int TN, int DT>
-__device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)[TM][TN], int m_base, int n_base, int lane) {
+// ULDS (256x256 GELU' dgrad only): the saved pre-activations of row groups i < 6 were staged in LDS under the main loop
+// (gemm_nt256_kernel, "u prefetch"); only the last two row groups are loaded from global memory here.
+//   u_r0: rows i = 0, 1 of both wave rows   [64 region rows x 512 B], region row = (wm ? 32 : 0) + 16 i + fr
+//   u_r1: rows i = 2..5                     [128 region rows x 512 B], region row = (wm ? 64 : 0) + 16 (i - 2) + fr
+// 16-B chunk c of a row lives at chunk c ^ (row & 15) (the DMA applied the same XOR to its source address).
+template <int EPI, int TM, int TN, int DT, bool ULDS = false>
+__device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)[TM][TN], int m_base, int n_base, int lane,
+                                              const char* u_r0 = nullptr, const char* u_r1 = nullptr, int wm = 0, int wn = 0) {
     static_assert(TN % 2 == 0, "column groups are exchanged in pairs");
     constexpr bool HAS_BIAS = EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 ||
                               EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16;
@@ -117,6 +123,7 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
     if (GELU_BWD) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if (ULDS && i < 6) continue;
             const int m = m_base + i * 16 + fr;
 #pragma unroll
             for (int jp = 0; jp < TN / 2; ++jp)
@@ -131,7 +138,14 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
         if (GELU_BWD) {
 #pragma unroll
             for (int jp = 0; jp < TN / 2; ++jp) {
-                uint4 q = uq[GELU_BWD ? i : 0][GELU_BWD ? jp : 0];
+                uint4 q;
+                if (ULDS && i < 6) {
+                    const char* reg = i < 2 ? u_r0 + ((wm ? 32 : 0) + i * 16 + fr) * 512 : u_r1 + ((wm ? 64 : 0) + (i - 2) * 16 + fr) * 512;
+                    const int c = (wn >> 3) + (g & 1) * 2 + (g >> 1) + jp * 4;
+                    q = *(const uint4*)(reg + ((c ^ fr) << 4));
+                } else {
+                    q = uq[GELU_BWD ? i : 0][GELU_BWD ? jp : 0];
+                }
                 lane_swap16(q.x, q.z);
                 lane_swap16(q.y, q.w);
                 pu[2 * jp][0] = q.x; pu[2 * jp][1] = q.y;
@@ -481,6 +495,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
     };
 
     const int nk = p.K >> 6;
+    // ---- u prefetch (GELU' dgrad): the epilogue multiplies by QuickGELU'(u) and u is a 128-KB tile that used to be loaded
+    // in the exposed epilogue (17.7 k of a 52.9 k-cycle tile, tools/gemm_stamps.py; one block per CU, so nothing overlaps
+    // it).  Three quarters of it now arrive by LDS-DMA under the main loop: rows i = 0,1 of every wave into the 32 KB of LDS
+    // beyond the two operand stages (issued in the prologue), rows i = 2..5 into the operand stage that is free from the
+    // barrier of the second-to-last K-step on; rows i = 6,7 stay register loads, requested first and consumed last.
+    constexpr bool UPF = EPI == SIG_EPI_DGELU_BF16;
+    const bf16_t* ubase = UPF ? (const bf16_t*)p.aux + (size_t)m0 * p.ldaux + n0 : nullptr;
+    auto dma_u = [&](int tile_row_of_region_row_lo, int region_row, char* region) {
+        // one 1-KB piece = region rows (region_row, region_row + 1); lane -> (row, physical chunk)
+        const int rr = region_row + (lane >> 5);
+        const int row = rr + tile_row_of_region_row_lo;                       // tile row (same low 4 bits as rr)
+        const int c = (lane & 31) ^ (rr & 15);
+        glds16_untracked_s(ubase, (unsigned)(row * p.ldaux + c * 8) * 2u, region + region_row * 512);
+    };
+    char* const u_r0 = smem + 2 * STAGE;
 #ifdef SIG_GEMM_STAMPS
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     SIG_STAMP(ts0);
@@ -488,7 +517,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
     // prologue: stage 0 complete, first fragments, first two pieces of stage 1
 #pragma unroll
     for (int j = 0; j < 4; ++j) { dma_a(j, 0, 0); dma_b(j, 0, 0); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (UPF) {
+        // issued AFTER the operand pieces so that the first barrier only waits for those (vmcnt retires in order: the four u
+        // pieces, which come from HBM at ~7 k cycles, stay in flight under the first K-step)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // region rows 0..31 -> tile rows 0..31, 32..63 -> 128..159
+            const int rlo = (wave * 4 + j) * 2;
+            dma_u(rlo < 32 ? 0 : 96, rlo, u_r0);
+        }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 #ifdef SIG_GEMM_STAMPS
     SIG_STAMP(ts1);
@@ -506,6 +546,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
     // peeled copies.  Needs nk >= 2.  LDS returns in order, so "lgkmcnt(n)" = everything but the newest n reads landed.
     auto step = [&](int kt, auto more_c, auto more2_c) {
         constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+        constexpr bool U_ISSUE = UPF && MORE && !MORE2;      // second-to-last K-step: its stage is free after the barrier
+        constexpr bool U_FLYING = UPF && !MORE;              // last K-step: nothing but the u pieces is in flight
         const int st = kt & 1;
         // P0: outstanding aX,bX (8) + aY (4)
         rd_a(st, 0, H1{}, aY);
@@ -528,7 +570,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
         mma(0, aX, bY);
         __builtin_amdgcn_sched_barrier(0);
         // stage boundary: this wave's DMA pieces of the next stage landed, all its reads of this stage returned
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(aY[0]), "+v"(aY[1]), "+v"(aY[2]), "+v"(aY[3])::"memory");
+        if (U_FLYING) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aY[0]), "+v"(aY[1]), "+v"(aY[2]), "+v"(aY[3])::"memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(aY[0]), "+v"(aY[1]), "+v"(aY[2]), "+v"(aY[3])::"memory");
         __builtin_amdgcn_s_barrier();
         // P3
         if (MORE) {
@@ -536,6 +579,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
             rd_b(st ^ 1, 0, bX);
         }
         if (MORE2) { dma_a(0, kt + 2, st); dma_a(1, kt + 2, st); dma_a(2, kt + 2, st); dma_a(3, kt + 2, st); }
+        if (U_ISSUE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {      // region rows 0..63 -> tile rows 32..95, 64..127 -> 160..223
+                const int rlo = (wave * 8 + j) * 2;
+                dma_u(rlo < 64 ? 32 : 96, rlo, smem + st * STAGE);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma(1, aY, bY);
         __builtin_amdgcn_sched_barrier(0);
@@ -550,7 +600,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
     SIG_STAMP(ts2);
 #endif
     // ---- epilogue: straight from the accumulator registers, no LDS and no barrier ----
-    epilogue_regs<EPI, 8, 4, DT>(p, acc, m0 + wm, n0 + wn, lane);
+    if constexpr (UPF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's u pieces (issued >= one K-step ago) landed
+        __builtin_amdgcn_s_barrier();                         // ... and everybody else's
+        epilogue_regs<EPI, 8, 4, DT, true>(p, acc, m0 + wm, n0 + wn, lane, u_r0, smem + ((nk - 2) & 1) * STAGE, wm, wn);
+    } else {
+        epilogue_regs<EPI, 8, 4, DT>(p, acc, m0 + wm, n0 + wn, lane);
+    }
 #ifdef SIG_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SIG_STAMP(ts3);
@@ -636,11 +692,13 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     if (big) {
         static bool attr256 = false;
         if (!attr256) {
-            (void)hipFuncSetAttribute((const void*)&gemm_nt256_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute((const void*)&gemm_nt256_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             attr256 = true;
         }
         p.band = choose_band(p.N >> 8, p.K, 256);
-        hipLaunchKernelGGL((gemm_nt256_kernel<EPI, DT>), dim3((mp >> 8) * (p.N >> 8)), dim3(512), 131072, st, p);
+        // (the GELU' dgrad stages a quarter of the saved pre-activation tile in the 32 KB beyond the two operand stages)
+        const int lds256 = EPI == SIG_EPI_DGELU_BF16 ? 163840 : 131072;
+        hipLaunchKernelGGL((gemm_nt256_kernel<EPI, DT>), dim3((mp >> 8) * (p.N >> 8)), dim3(512), lds256, st, p);
     } else {
         static bool attr_done = false;
         if (!attr_done) {

@@ -101,6 +101,29 @@ def test_config_node():
         c.MODEL.TOPK = 1
 
 
+@pytest.mark.parametrize("name,hw,topk,direct,k,lr", [("RGBNT201", [256, 128], 80, 1, 8, 3.5e-4), ("RGBNT100", [128, 256], 112, 0, 16, 7e-4),
+                                                       ("MSVR310", [128, 256], 64, 0, 4, 5e-6)])
+def test_shipped_configs_build_the_reference_parameter_tree(name, hw, topk, direct, k, lr):
+    """The three configs the reference ships (configs/*/Signal.yml): every one merges, builds the parameter tree with the
+    reference's 91.17 M / per-modality-head layout, and drives make_optimizer's name rules (MSVR310: classifier lr x100)."""
+    from signal_amd.config import get_cfg_defaults
+    from signal_amd.modeling import make_frame
+    from signal_amd.solver.make_optimizer import param_hyper
+    c = get_cfg_defaults()
+    c.merge_from_file(os.path.join(ROOT, "configs", name, "Signal.yml"))
+    assert (c.INPUT.SIZE_TRAIN, c.MODEL.TOPK, c.MODEL.DIRECT, c.DATALOADER.NUM_INSTANCE, c.SOLVER.BASE_LR) == (hw, topk, direct, k, lr)
+    model = make_frame(c, 171, 4, 0)
+    n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert model.clip_vision_encoder.base.positional_embedding.shape == (129, 768)
+    if direct:
+        assert n == 91_166_209                              # the reference's log line for RGBNT201 (SURVEY section 6)
+        assert model.classifier.weight.shape == (171, 1536)
+    else:
+        assert all(hasattr(model, f"classifier_{m}") and getattr(model, f"classifier_{m}").weight.shape == (171, 512) for m in "rnt")
+    want = (100 * lr, 1e-4) if name == "MSVR310" else (lr, 1e-4)
+    assert param_hyper(c, "classifier_var.weight") == want
+
+
 def test_loss_factory_refuses_host_tensors_and_assembles_like_the_processor():
     """The ReID loss itself runs in HIP only (parity vs G6: tests/test_train_gpu.py; oracle vs G6: test_oracle_golden);
     here: the factory contract, the loud failure on host tensors, and the loss assembly of processor.py:244-256."""

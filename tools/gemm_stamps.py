@@ -19,13 +19,14 @@ _lib._lib = None
 L = _lib.load()
 dev = torch.device("cuda:0")
 M = 24768; Mp = ops.pad_rows(M)
-for name, n, k, epi in [("qkv", 2304, 768, ops.BIAS_BF16), ("c_fc", 3072, 768, ops.BIAS_GELU_BF16), ("c_proj", 768, 3072, ops.BIAS_RES_F32)]:
+for name, n, k, epi in [("qkv", 2304, 768, ops.BIAS_BF16), ("c_fc", 3072, 768, ops.BIAS_GELU_BF16), ("c_fc_inf", 3072, 768, ops.BIAS_GELU_BF16),
+                        ("dgelu", 3072, 768, ops.DGELU_BF16), ("c_proj", 768, 3072, ops.BIAS_RES_F32)]:
     a = torch.randn(Mp, k, device=dev).to(torch.bfloat16); w = (torch.randn(n, k, device=dev) * .02).to(torch.bfloat16)
     bias = torch.randn(n, device=dev); f32 = epi == ops.BIAS_RES_F32
     out = torch.zeros(Mp, n, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
-    aux = torch.zeros(Mp, n, device=dev, dtype=torch.bfloat16) if epi == ops.BIAS_GELU_BF16 else None
+    aux = torch.randn(Mp, n, device=dev).to(torch.bfloat16) if (epi == ops.BIAS_GELU_BF16 and name != "c_fc_inf") or epi == ops.DGELU_BF16 else None
     for _ in range(3):
-        ops.gemm_nt(a, w, M, epi, out, bias=bias, res=out if f32 else None, aux=aux)
+        ops.gemm_nt(a, w, M, epi, out, bias=None if epi == ops.DGELU_BF16 else bias, res=out if f32 else None, aux=aux)
     torch.cuda.synchronize()
     T = int(os.environ.get('SIG_GEMM_TILE', '128'))
     nb = min(8192, (Mp // T) * (n // T))
