@@ -1272,17 +1272,18 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
-// per-(device, stream) scratch for the partial tiles (<= 256 blocks x 256 KB); grown on demand, never freed
-static float* tn_workspace(hipStream_t st, size_t bytes) {
-    struct Ent { int dev; hipStream_t st; float* p; size_t bytes; };
-    static Ent ents[16];
+// per-(device, stream, slot) scratch (slot 0: the partial tiles of the 256x256 TN kernel, <= 256 blocks x 256 KB; slot 1: the
+// per-block column sums of the LayerNorm backward); grown on demand, never freed
+float* sig_stream_scratch(hipStream_t st, size_t bytes, int slot) {
+    struct Ent { int dev; hipStream_t st; int slot; float* p; size_t bytes; };
+    static Ent ents[32];
     static int n = 0;
     static std::mutex mu;   // forward runs on the caller's thread, backward on autograd's
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     for (int i = 0; i < n; ++i)
-        if (ents[i].st == st && ents[i].dev == dev) {
+        if (ents[i].st == st && ents[i].dev == dev && ents[i].slot == slot) {
             if (ents[i].bytes < bytes) {
                 (void)hipStreamSynchronize(st);
                 (void)hipFree(ents[i].p);
@@ -1291,12 +1292,13 @@ static float* tn_workspace(hipStream_t st, size_t bytes) {
             }
             return ents[i].p;
         }
-    if (n == 16) return nullptr;   // more (device, stream) pairs than slots: the caller falls back to atomics
+    if (n == 32) return nullptr;   // more (device, stream) pairs than slots: the caller falls back to atomics
     float* ptr = nullptr;
     if (hipMalloc((void**)&ptr, bytes) != hipSuccess) return nullptr;
-    ents[n++] = {dev, st, ptr, bytes};
+    ents[n++] = {dev, st, slot, ptr, bytes};
     return ptr;
 }
+static float* tn_workspace(hipStream_t st, size_t bytes) { return sig_stream_scratch(st, bytes, 0); }
 
 template <int DT>
 static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {

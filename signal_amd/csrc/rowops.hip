@@ -77,7 +77,7 @@ int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* be
 // one atomic per column per workgroup).
 // ------------------------------------------------------------------------------------------------
 #ifndef LN_BWD_WPB
-#define LN_BWD_WPB 4    // waves per block of layernorm_bwd_kernel
+#define LN_BWD_WPB 8    // waves per block of layernorm_bwd_kernel (8 x 384 blocks: half the partial rows of 4 x 768 for the same waves)
 #endif
 template <bool DY_BF16, int NV, bool SUMX, int WPB>
 __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
@@ -85,13 +85,14 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dxf, bf16_t* __restrict__ dxb,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D,
-                                                            float* __restrict__ dxsum, int dt) {
+                                                            float* __restrict__ dxsum, int dt, float* __restrict__ part) {
     // NV = float4 per lane (D <= 256*NV): sized to the row so the per-lane accumulators stay small (more waves per SIMD).
     // Column sums (dgamma, dbeta, optional sum of dx): every wave parks its accumulators in its own LDS slice (plain
     // b128 stores), the block adds the slices and issues one global atomic per column.  That flush runs at the
     // memory-side atomic rate and the LDS slices cap residency, so the launcher uses FEW blocks with many rows each
-    // (in-model, D = 768, M = 24768: 2048 blocks 98 us, 512 blocks 71 us, 768 blocks 67 us; LDS float atomics instead of slices were
-    // slower at every block count, 16-wave blocks too).
+    // (in-model, D = 768, M = 24768, atomics flush: 2048 blocks 98 us, 512 blocks 71 us, 768 blocks 67 us; LDS float atomics
+    // instead of slices were slower at every block count.  Round 2: per-block partial rows + ln_bwd_reduce_kernel instead of the
+    // atomics: 4 x 768 blocks 55.9 + 9.5 us, 8 x 384 blocks 57.6 + 5.9 us = 63.5 against 68.5, and deterministic.)
     __shared__ float red[SUMX ? 3 : 2][WPB][256 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool sums = dgamma != nullptr || SUMX;
@@ -176,25 +177,58 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
             bsum += red[1][w][c];
             if (SUMX) xs += red[SUMX ? 2 : 0][w][c];
         }
-        if (dgamma) {
-            atomicAdd(dgamma + c, g);
-            atomicAdd(dbeta + c, bsum);
+        if (part) {
+            // this block's column sums go to its own row of a scratch matrix with plain stores; ln_bwd_reduce_kernel adds the
+            // rows in a fixed order.  (One global atomic per column and block: 768 blocks hammering the same 2304 addresses
+            // cost ~24 ns per block, 19 of the kernel's 67 us, and made these gradients order-dependent.)
+            float* pr = part + (size_t)blockIdx.x * 3 * D;
+            pr[c] = g;
+            pr[D + c] = bsum;
+            pr[2 * D + c] = xs;
+        } else {
+            if (dgamma) {
+                atomicAdd(dgamma + c, g);
+                atomicAdd(dbeta + c, bsum);
+            }
+            if (SUMX) atomicAdd(dxsum + c, xs);
         }
-        if (SUMX) atomicAdd(dxsum + c, xs);
+    }
+}
+
+// out_k[c] += sum over blocks b of part[b][k][c], k = 0 (dgamma), 1 (dbeta), 2 (dx column sums): a 1024-thread block owns 64
+// columns of one array; 16 row chunks are summed in parallel and combined through LDS in chunk order (deterministic)
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int D, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dxsum) {
+    __shared__ float sm[16][64];
+    const int k = blockIdx.y;
+    float* out = k == 0 ? dgamma : (k == 1 ? dbeta : dxsum);
+    if (!out) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), chunk = threadIdx.x >> 6;
+    const int per = (nblocks + 15) >> 4, b0 = chunk * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    float acc = 0.f;
+    if (c < D)
+        for (int b = b0; b < b1; ++b) acc += part[((size_t)b * 3 + k) * D + c];
+    sm[chunk][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (chunk == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sm[q][threadIdx.x & 63];
+        out[c] += t;
     }
 }
 
 template <bool DY_BF16, int NV>
 static void launch_ln_bwd(int blocks, hipStream_t st, const void* dy, const float* x, const float* gamma, const float* mean,
                           const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma, float* dbeta, int M,
-                          int D, float* dx_colsum, int dt) {
+                          int D, float* dx_colsum, int dt, float* part) {
     constexpr int WPB = LN_BWD_WPB;
     if (dx_colsum)
         hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, true, WPB>), dim3(blocks), dim3(64 * WPB), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt);
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part);
     else
         hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, false, WPB>), dim3(blocks), dim3(64 * WPB), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt);
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part);
 }
 
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
@@ -206,12 +240,15 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     SIG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
     // rows per wave made EQUAL: with a fixed block count 24768 rows over 768 x 4 waves is 8.06 rows per wave -- 6 % of the
     // waves walk a ninth row while the chip idles.  k = rows per wave for ~cap blocks, then exactly ceil(M / (4k)) blocks.
-    static int cap = 0;
-    if (!cap) { const char* e = getenv("SIG_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 768; }
+    static int cap = 0, use_part = -1;
+    if (!cap) { const char* e = getenv("SIG_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 384; }
+    if (use_part < 0) { const char* e = getenv("SIG_LN_BWD_ATOMICS"); use_part = e && atoi(e) ? 0 : 1; }
     const int k = sig_ceil_div(M, LN_BWD_WPB * cap);
     int blocks = sig_ceil_div(M, LN_BWD_WPB * (k > 0 ? k : 1));
     const int nv = (D + 255) / 256;
-#define SIG_LN(BF, NV_) launch_ln_bwd<BF, NV_>(blocks, st, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt)
+    const bool sums = dgamma != nullptr || dx_colsum != nullptr;
+    float* part = (sums && use_part && blocks > 16) ? sig_stream_scratch(st, (size_t)blocks * 3 * D * sizeof(float), 1) : nullptr;
+#define SIG_LN(BF, NV_) launch_ln_bwd<BF, NV_>(blocks, st, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part)
     if (dy_is_bf16) {
         if (nv == 1) SIG_LN(true, 1); else if (nv == 2) SIG_LN(true, 2); else if (nv == 3) SIG_LN(true, 3); else SIG_LN(true, 4);
     } else {
@@ -219,6 +256,10 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     }
 #undef SIG_LN
     SIG_CHECK_LAUNCH("layernorm_bwd");
+    if (part) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(sig_ceil_div(D, 64), 3), dim3(1024), 0, st, part, blocks, D, dgamma, dbeta, dx_colsum);
+        SIG_CHECK_LAUNCH("layernorm_bwd_reduce");
+    }
     return 0;
 }
 

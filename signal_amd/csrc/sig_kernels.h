@@ -52,6 +52,8 @@ struct SigGemmTN {
     int dt;           // SIG_DT_BF16 / SIG_DT_F16: type of P and Q
 };
 int sig_launch_gemm_tn(const SigGemmTN& p, hipStream_t st);
+// library-owned scratch per (device, stream, slot): nullptr when it cannot be had (callers then fall back to atomics)
+float* sig_stream_scratch(hipStream_t st, size_t bytes, int slot);
 
 // ---- row-wise kernels (rowops.hip) ----------------------------------------------------------------
 int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y_bf16, float* y_f32,
