@@ -104,8 +104,10 @@ class Signal(nn.Module):
     def _encode(self, x, cam_label, training=True):
         imgs = [x["RGB"], x["NI"], x["TI"]]
         dev = imgs[0].device
-        self.hip.prepare(dev)
         B = imgs[0].shape[0]
+        if B == 0 or any(im.dim() != 4 or im.shape[0] != B for im in imgs):
+            raise ValueError(f"expected three [B,3,H,W] image tensors with the same B >= 1, got {[tuple(im.shape) for im in imgs]}")
+        self.hip.prepare(dev)
         cam = None
         if self.clip_vision_encoder.cv_embed_sign:
             if cam_label is None:

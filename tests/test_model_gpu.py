@@ -240,3 +240,32 @@ def test_inference_odd_batches_vs_oracle(dev, B, tag, dtype):
         assert (hip_mask == ref_mask).float().mean().item() > 0.985
         if same.any():
             assert rel_err(feat[same][:, 1536:], ref[same][:, 1536:]) < tol
+
+
+def test_maximum_batch_and_batch_independence(dev):
+    """B = 128 per GPU (RGBNT100's IMS_PER_BATCH, the ReID head's maximum) at the RGBNT100 geometry, fp16 operands:
+    M = 49536 token rows, 194 full 256-row tiles.  Size-independent property instead of a 128-triplet CPU oracle run: at
+    inference every triplet is independent of its batch mates, and every kernel reduces over K in an order that does not
+    depend on M -- so the features of a triplet computed inside the big batch must equal those computed in a batch of 3
+    (different tile counts, different kernels for the ragged tail), and those are pinned to the oracle."""
+    ocfg = O.rgbnt100_config()
+    sd = O.init_state_dict(ocfg, seed=21)
+    model = build(ocfg, sd, dev, "fp16")
+    img, _, cam = O.synthetic_batch(ocfg, 128, seed=22)
+    x = {k: v.to(dev) for k, v in img.items()}
+    with torch.no_grad():
+        big = model(x, cam_label=cam.to(dev), training=False)
+        idx = torch.tensor([0, 77, 127])
+        small = model({k: v[idx.to(dev)].contiguous() for k, v in x.items()}, cam_label=cam[idx].to(dev), training=False)
+        ref = O.signal_forward_infer(sd, ocfg, {k: v[idx] for k, v in img.items()}, cam[idx])
+    assert big.shape == (128, 3072) and torch.isfinite(big).all()
+    d = rel_err(big[idx.to(dev)][:, :1536], small[:, :1536])
+    print(f"[max batch] B=128 vs B=3, same triplets: backbone features differ by {d:.2e} (bit-identical: {torch.equal(big[idx.to(dev)][:, :1536], small[:, :1536])})")
+    assert d < 1e-5
+    assert rel_err(big[idx.to(dev)][:, 1536:], small[:, 1536:]) < 1e-5          # SIM: selection + interaction per sample
+    assert rel_err(small[:, :1536], ref[:, :1536]) < FEAT_TOL["fp16"]
+    assert rel_err(big[idx.to(dev)][:, :1536], ref[:, :1536]) < FEAT_TOL["fp16"]
+    with pytest.raises(ValueError):
+        model({k: v[:0] for k, v in x.items()}, cam_label=cam[:0].to(dev), training=False)      # empty batch: loud, before any launch
+    with pytest.raises(ValueError):
+        model({"RGB": x["RGB"][:2], "NI": x["NI"][:3], "TI": x["TI"][:2]}, cam_label=cam[:2].to(dev), training=False)   # ragged modalities
