@@ -284,7 +284,7 @@ typedef struct SigLamActs {         /* leading [3] = modality; R = B*(L-1) rows 
     float *a2pre, *offs, *samp;     /* f32 [3][B,P,512], [3][B,P,3] (o, p_y, p_x), [3][B,P,512] ; P = (h/4)*(w/4) <= 8 */
     float* loss;                    /* [1 + 64]: loss[0] = the LAM loss, the rest = per-block partial sums (scratch) */
 } SigLamActs;
-typedef struct SigLamScratch { uint16_t *da1pre, *dq; float* dx; } SigLamScratch;   /* [R,512] each, pad rows zero */
+typedef struct SigLamScratch { uint16_t *da1pre, *dq; float* dx; } SigLamScratch;   /* da1pre [3][R padded,512]; dq, dx [R padded,512]; pad rows zero */
 int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, int dtype, const SigDasParams* p3, const SigLamActs* a,
                 void* stream);
 int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, int dtype, const SigDasParams* p3, const SigDasGrads* g3,

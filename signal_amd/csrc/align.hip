@@ -262,15 +262,22 @@ struct LamGeom { int h, w, Hk, Wk; };
 //   a2pre  f32  [B, P, 512]   depthwise pre-activation (kept for backward), P = Hk*Wk
 //   offs   f32  [B, P, 3]     raw offset o, p_y, p_x
 //   samp   f32  [B, P, 512]   sampled feature
-__global__ __launch_bounds__(512) void lam_tail_fwd_kernel(const float* __restrict__ tokens, int m, int L, int B, LamGeom g,
-                                                           const bf16_t* __restrict__ a1, const float* __restrict__ wd,
-                                                           const float* __restrict__ bd, const float* __restrict__ w4,
-                                                           float* __restrict__ a2pre, float* __restrict__ offs,
-                                                           float* __restrict__ samp, int dt) {
+// (grid = (B, 3): the three modalities' tails are ONE launch -- 64 blocks per launch left three quarters of the chip idle)
+__global__ __launch_bounds__(512) void lam_tail_fwd_kernel(const float* __restrict__ tokens, int L, int B, LamGeom g,
+                                                           const bf16_t* __restrict__ a1_, size_t a_stride, SigLamTailPtrs tp,
+                                                           float* __restrict__ a2pre_, float* __restrict__ offs_,
+                                                           float* __restrict__ samp_, int dt) {
     __shared__ float red[8][8];
     __shared__ float pos[8][2];
-    const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const int b = blockIdx.x, m = blockIdx.y, c = threadIdx.x, lane = c & 63, wave = c >> 6;
     const int P = g.Hk * g.Wk, Lp = L - 1;
+    const bf16_t* __restrict__ a1 = a1_ + (size_t)m * a_stride;
+    const float* __restrict__ wd = tp.wd[m];
+    const float* __restrict__ bd = tp.bd[m];
+    const float* __restrict__ w4 = tp.w4[m];
+    float* __restrict__ a2pre = a2pre_ + (size_t)m * B * P * AL_D;
+    float* __restrict__ offs = offs_ + (size_t)m * B * P * 3;
+    float* __restrict__ samp = samp_ + (size_t)m * B * P * AL_D;
     float wdc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) wdc[k] = wd[c * 16 + k];
@@ -354,18 +361,27 @@ __global__ __launch_bounds__(64) void lam_loss_final_kernel(float* __restrict__ 
 // backward of the tail for one (sample, modality).  Writes da1pre bf16 [B*Lp,512] (gradient of the conv_offset.0
 // pre-activation, i.e. already multiplied by GELU'), accumulates dwd[512,16], dbd[512], dw4[512] and the bilinear
 // gradient w.r.t. the sampled feature map into dtokens.
-__global__ __launch_bounds__(512) void lam_tail_bwd_kernel(const float* __restrict__ tokens, int m, int L, int B, LamGeom g,
-                                                           const bf16_t* __restrict__ a1, const bf16_t* __restrict__ a1pre,
-                                                           const float* __restrict__ wd, const float* __restrict__ w4,
-                                                           const float* __restrict__ a2pre, const float* __restrict__ offs,
+__global__ __launch_bounds__(512) void lam_tail_bwd_kernel(const float* __restrict__ tokens, int L, int B, LamGeom g,
+                                                           const bf16_t* __restrict__ a1_, const bf16_t* __restrict__ a1pre_, size_t a_stride,
+                                                           SigLamTailPtrs tp, const float* __restrict__ a2pre_, const float* __restrict__ offs_,
                                                            const float* __restrict__ samp_all, size_t nsamp,
-                                                           const float* __restrict__ dloss, bf16_t* __restrict__ da1pre,
-                                                           float* __restrict__ dwd, float* __restrict__ dbd, float* __restrict__ dw4,
-                                                           float* __restrict__ dtokens, float* __restrict__ part, int dt) {
+                                                           const float* __restrict__ dloss, bf16_t* __restrict__ da1pre_,
+                                                           float* __restrict__ dtokens, float* __restrict__ part_, int dt) {
     __shared__ float red[8][16];
     __shared__ float dofs[8];
-    const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const int b = blockIdx.x, m = blockIdx.y, c = threadIdx.x, lane = c & 63, wave = c >> 6;
     const int P = g.Hk * g.Wk, Lp = L - 1;
+    const bf16_t* __restrict__ a1 = a1_ + (size_t)m * a_stride;
+    const bf16_t* __restrict__ a1pre = a1pre_ + (size_t)m * a_stride;
+    bf16_t* __restrict__ da1pre = da1pre_ + (size_t)m * a_stride;
+    const float* __restrict__ wd = tp.wd[m];
+    const float* __restrict__ w4 = tp.w4[m];
+    float* __restrict__ dwd = tp.dwd[m];
+    float* __restrict__ dbd = tp.dbd[m];
+    float* __restrict__ dw4 = tp.dw4[m];
+    const float* __restrict__ a2pre = a2pre_ + (size_t)m * nsamp;
+    const float* __restrict__ offs = offs_ + (size_t)m * B * P * 3;
+    float* __restrict__ part = part_ ? part_ + (size_t)m * B * (18 * AL_D) : nullptr;
     const float scale = dloss[0] * 2.0f / (3.0f * (float)nsamp);
     const float* x = tokens + ((size_t)(m * B + b) * L + 1) * AL_D + c;
     float* dx = dtokens + ((size_t)(m * B + b) * L + 1) * AL_D + c;
@@ -460,10 +476,13 @@ __global__ __launch_bounds__(512) void lam_tail_bwd_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void lam_tail_reduce_kernel(const float* __restrict__ part, int B, float* __restrict__ dwd,
-                                                              float* __restrict__ dbd, float* __restrict__ dw4) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void lam_tail_reduce_kernel(const float* __restrict__ part_, int B, SigLamTailPtrs tp) {
+    const int i = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (i >= 18 * AL_D) return;
+    const float* __restrict__ part = part_ + (size_t)m * B * (18 * AL_D);
+    float* dwd = tp.dwd[m];
+    float* dbd = tp.dbd[m];
+    float* dw4 = tp.dw4[m];
     float a = 0.f;
     for (int b = 0; b < B; ++b) a += part[(size_t)b * (18 * AL_D) + i];
     float* dst = i < 16 * AL_D ? dwd + i : (i < 17 * AL_D ? dbd + (i - 16 * AL_D) : dw4 + (i - 17 * AL_D));
@@ -489,13 +508,13 @@ static int lam_geom(int h, int w, LamGeom* g) {
     SIG_CHECK_ARG(g->Hk * g->Wk <= 8, "lam: at most 8 sampling points per map are supported (got %d)", g->Hk * g->Wk);
     return 0;
 }
-int sig_launch_lam_tail_fwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const float* wd,
-                            const float* bd, const float* w4, float* a2pre, float* offs, float* samp, int dt, hipStream_t st) {
+int sig_launch_lam_tail_fwd(const float* tokens, int B, int L, int h, int w, const bf16_t* a1, size_t a_stride, const SigLamTailPtrs& tp,
+                            float* a2pre, float* offs, float* samp, int dt, hipStream_t st) {
     SIG_CHECK_DT(dt, "lam_tail_fwd");
     LamGeom g;
     if (int rc = lam_geom(h, w, &g)) return rc;
     SIG_CHECK_ARG(h * w == L - 1, "lam: grid %dx%d does not match %d patches", h, w, L - 1);
-    hipLaunchKernelGGL(lam_tail_fwd_kernel, dim3(B), dim3(512), 0, st, tokens, m, L, B, g, a1, wd, bd, w4, a2pre, offs, samp, dt);
+    hipLaunchKernelGGL(lam_tail_fwd_kernel, dim3(B, 3), dim3(512), 0, st, tokens, L, B, g, a1, a_stride, tp, a2pre, offs, samp, dt);
     SIG_CHECK_LAUNCH("lam_tail_fwd");
     return 0;
 }
@@ -508,19 +527,18 @@ int sig_launch_lam_loss(const float* samp, size_t n, float* loss, hipStream_t st
     SIG_CHECK_LAUNCH("lam_loss");
     return 0;
 }
-int sig_launch_lam_tail_bwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre,
-                            const float* wd, const float* w4, const float* a2pre, const float* offs, const float* samp_all,
-                            size_t nsamp, const float* dloss, bf16_t* da1pre, float* dwd, float* dbd, float* dw4, float* dtokens,
-                            int dt, hipStream_t st, float* partials) {
+int sig_launch_lam_tail_bwd(const float* tokens, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre, size_t a_stride,
+                            const SigLamTailPtrs& tp, const float* a2pre, const float* offs, const float* samp_all, size_t nsamp,
+                            const float* dloss, bf16_t* da1pre, float* dtokens, int dt, hipStream_t st, float* partials) {
     SIG_CHECK_DT(dt, "lam_tail_bwd");
     LamGeom g;
     if (int rc = lam_geom(h, w, &g)) return rc;
-    // partials: caller scratch of >= B * 18 * 512 floats (nullptr -> contended atomics straight into the gradients)
-    hipLaunchKernelGGL(lam_tail_bwd_kernel, dim3(B), dim3(512), 0, st, tokens, m, L, B, g, a1, a1pre, wd, w4, a2pre, offs, samp_all,
-                       nsamp, dloss, da1pre, dwd, dbd, dw4, dtokens, partials, dt);
+    // partials: caller scratch of >= 3 * B * 18 * 512 floats (nullptr -> contended atomics straight into the gradients)
+    hipLaunchKernelGGL(lam_tail_bwd_kernel, dim3(B, 3), dim3(512), 0, st, tokens, L, B, g, a1, a1pre, a_stride, tp, a2pre, offs, samp_all,
+                       nsamp, dloss, da1pre, dtokens, partials, dt);
     SIG_CHECK_LAUNCH("lam_tail_bwd");
     if (partials) {
-        hipLaunchKernelGGL(lam_tail_reduce_kernel, dim3(sig_ceil_div(18 * AL_D, 256)), dim3(256), 0, st, partials, B, dwd, dbd, dw4);
+        hipLaunchKernelGGL(lam_tail_reduce_kernel, dim3(sig_ceil_div(18 * AL_D, 256), 3), dim3(256), 0, st, partials, B, tp);
         SIG_CHECK_LAUNCH("lam_tail_reduce");
     }
     return 0;

@@ -7,48 +7,86 @@
 #include "sig_kernels.h"
 
 // ---- BatchNorm1d, training mode: batch statistics (biased var for the normalisation, unbiased for running_var) ----
+// Block = 64 columns x 4 row lanes (rows ty, ty + 4, ...): a column's B <= 128 values stay in registers over the three
+// passes and the row lanes are combined through LDS in a fixed order.  (One thread per column walking the rows three times
+// was 6 blocks of serialized loads: 32 us for 400 KB.)
+#define BN_MAXR 32     // rows per row lane: B <= 128
+__device__ __forceinline__ float bn_sum4(float v, float (*red)[64], int tx, int ty) {
+    __syncthreads();
+    red[ty][tx] = v;
+    __syncthreads();
+    return (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                      float* __restrict__ run_mean, float* __restrict__ run_var, float momentum, float eps,
                                                      int B, int F, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= F) return;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool ok = c < F;
+    float v[BN_MAXR];
     float s = 0.f;
-    for (int r = 0; r < B; ++r) s += x[(size_t)r * F + c];
-    const float mu = s / B;
-    float q = 0.f;
-    for (int r = 0; r < B; ++r) {
-        const float d = x[(size_t)r * F + c] - mu;
-        q += d * d;
+#pragma unroll
+    for (int i = 0; i < BN_MAXR; ++i) {
+        const int r = ty + 4 * i;
+        v[i] = (ok && r < B) ? x[(size_t)r * F + c] : 0.f;
+        s += v[i];
     }
+    const float mu = bn_sum4(s, red, tx, ty) / B;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < BN_MAXR; ++i)
+        if (ty + 4 * i < B) { const float d = v[i] - mu; q += d * d; }
+    q = bn_sum4(q, red, tx, ty);
+    if (!ok) return;
     const float var = q / B, rs = rsqrtf(var + eps);
-    mean[c] = mu;
-    rstd[c] = rs;
-    if (run_mean) {
-        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
-        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (B > 1 ? q / (B - 1) : var);
+    if (ty == 0) {
+        mean[c] = mu;
+        rstd[c] = rs;
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * (B > 1 ? q / (B - 1) : var);
+        }
     }
     const float g = w[c], bb = b[c];
-    for (int r = 0; r < B; ++r) y[(size_t)r * F + c] = (x[(size_t)r * F + c] - mu) * rs * g + bb;
+#pragma unroll
+    for (int i = 0; i < BN_MAXR; ++i) {
+        const int r = ty + 4 * i;
+        if (r < B) y[(size_t)r * F + c] = (v[i] - mu) * rs * g + bb;
+    }
 }
-// dx = g*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)) ; dw += sum dy*xhat ; db += sum dy (db may be NULL: frozen bias)
+// dx += g*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)) ; dw += sum dy*xhat ; db += sum dy (db may be NULL: frozen bias)
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, int B, int F,
                                                      float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= F) return;
-    const float mu = mean[c], rs = rstd[c];
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool ok = c < F;
+    const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f;
+    float xh[BN_MAXR], d[BN_MAXR];
     float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < B; ++r) {
-        const float d = dy[(size_t)r * F + c];
-        s1 += d;
-        s2 += d * (x[(size_t)r * F + c] - mu) * rs;
+#pragma unroll
+    for (int i = 0; i < BN_MAXR; ++i) {
+        const int r = ty + 4 * i;
+        const bool live = ok && r < B;
+        d[i] = live ? dy[(size_t)r * F + c] : 0.f;
+        xh[i] = live ? (x[(size_t)r * F + c] - mu) * rs : 0.f;
+        s1 += d[i];
+        s2 += d[i] * xh[i];
     }
-    if (dw) atomicAdd(dw + c, s2);
-    if (db) atomicAdd(db + c, s1);
+    s1 = bn_sum4(s1, red, tx, ty);
+    s2 = bn_sum4(s2, red, tx, ty);
+    if (!ok) return;
+    if (ty == 0) {                   // the only writer of this column: a plain accumulate, no atomics
+        if (dw) dw[c] += s2;
+        if (db) db[c] += s1;
+    }
     const float g = w[c], m1 = s1 / B, m2 = s2 / B;
-    for (int r = 0; r < B; ++r) {
-        const float xh = (x[(size_t)r * F + c] - mu) * rs;
-        dx[(size_t)r * F + c] += g * rs * (dy[(size_t)r * F + c] - m1 - xh * m2);   // ACCUMULATES (triplet grad is already there)
+#pragma unroll
+    for (int i = 0; i < BN_MAXR; ++i) {
+        const int r = ty + 4 * i;
+        if (r < B) dx[(size_t)r * F + c] += g * rs * (d[i] - m1 - xh[i] * m2);   // ACCUMULATES (triplet grad is already there)
     }
 }
 
@@ -182,18 +220,35 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
     const int r = blockIdx.x;
     for (int a = threadIdx.x; a < B; a += 256) { sp[a] = pidx[a]; sn[a] = nidx[a]; sca[a] = coef[2 * a]; scn[a] = coef[2 * a + 1]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < F; c += 256) {
-        float acc = 0.f;
-        for (int a = 0; a < B; ++a) {
-            const int p = sp[a], n = sn[a];
-            if (a != r && p != r && n != r) continue;
-            const float xa = x[(size_t)a * F + c];
-            const float gp = sca[a] * (xa - x[(size_t)p * F + c]), gn = scn[a] * (xa - x[(size_t)n * F + c]);
-            if (a == r) acc += gp + gn;
-            if (p == r) acc -= gp;
-            if (n == r) acc -= gn;
+    constexpr int CPT = 8;           // columns per thread (F <= 2048); the loads of one anchor's rows are all in flight together
+    float acc[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) acc[i] = 0.f;
+    for (int a = 0; a < B; ++a) {    // anchor order = summation order (uniform branch: r is per block)
+        const int p = sp[a], n = sn[a];
+        if (a != r && p != r && n != r) continue;
+        const float ca = sca[a], cn = scn[a];
+        float xa[CPT], xp[CPT], xn[CPT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            const bool ok = c < F;
+            xa[i] = ok ? x[(size_t)a * F + c] : 0.f;
+            xp[i] = ok ? x[(size_t)p * F + c] : 0.f;
+            xn[i] = ok ? x[(size_t)n * F + c] : 0.f;
         }
-        dx[(size_t)r * F + c] += acc;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const float gp = ca * (xa[i] - xp[i]), gn = cn * (xa[i] - xn[i]);
+            if (a == r) acc[i] += gp + gn;
+            if (p == r) acc[i] -= gp;
+            if (n == r) acc[i] -= gn;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < F) dx[(size_t)r * F + c] += acc[i];
     }
 }
 
@@ -201,8 +256,8 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
 int sig_launch_bnneck_fwd(const float* x, const float* bn_w, const float* bn_b, float* run_mean, float* run_var, float momentum,
                           const float* cls_w, int B, int F, int C, float* y, float* mean, float* rstd, float* logits, hipStream_t st) {
     SIG_CHECK_ARG(x && bn_w && bn_b && cls_w && y && mean && rstd && logits, "bnneck_fwd: null pointer");
-    SIG_CHECK_ARG(B > 0 && F > 0 && (F & 3) == 0 && C > 0, "bnneck_fwd: bad shape B=%d F=%d C=%d", B, F, C);
-    hipLaunchKernelGGL(bn_fwd_kernel, dim3(sig_ceil_div(F, 256)), dim3(256), 0, st, x, bn_w, bn_b, run_mean, run_var, momentum, 1e-5f, B, F, y, mean, rstd);
+    SIG_CHECK_ARG(B > 0 && B <= 128 && F > 0 && (F & 3) == 0 && C > 0, "bnneck_fwd: bad shape B=%d (<= 128) F=%d C=%d", B, F, C);
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3(sig_ceil_div(F, 64)), dim3(256), 0, st, x, bn_w, bn_b, run_mean, run_var, momentum, 1e-5f, B, F, y, mean, rstd);
     SIG_CHECK_LAUNCH("bn_fwd");
     hipLaunchKernelGGL(dot_nt_kernel, dim3(sig_ceil_div(B * C, 4)), dim3(256), 0, st, y, cls_w, B, C, F, logits);
     SIG_CHECK_LAUNCH("classifier");
@@ -212,11 +267,12 @@ int sig_launch_bnneck_bwd(const float* x, const float* y, const float* bn_w, con
                           const float* dlogits, int B, int F, int C, float* dy_scratch, float* dx, float* dbn_w, float* dbn_b, float* dcls_w,
                           hipStream_t st) {
     SIG_CHECK_ARG(x && y && bn_w && mean && rstd && cls_w && dlogits && dy_scratch && dx && dcls_w, "bnneck_bwd: null pointer");
+    SIG_CHECK_ARG(B > 0 && B <= 128, "bnneck_bwd: batch %d must be in 1..128", B);
     hipLaunchKernelGGL(dot_tn_kernel, dim3(sig_ceil_div(C * F, 256)), dim3(256), 0, st, dlogits, y, B, C, F, dcls_w, 1);
     SIG_CHECK_LAUNCH("classifier_wgrad");
     hipLaunchKernelGGL(dot_nn_kernel, dim3(sig_ceil_div(B * F, 256)), dim3(256), 0, st, dlogits, cls_w, B, C, F, dy_scratch);
     SIG_CHECK_LAUNCH("classifier_dgrad");
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3(sig_ceil_div(F, 256)), dim3(256), 0, st, x, dy_scratch, bn_w, mean, rstd, B, F, dx, dbn_w, dbn_b);
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(sig_ceil_div(F, 64)), dim3(256), 0, st, x, dy_scratch, bn_w, mean, rstd, B, F, dx, dbn_w, dbn_b);
     SIG_CHECK_LAUNCH("bn_bwd");
     return 0;
 }
@@ -224,7 +280,7 @@ int sig_launch_reid_loss(const float* logits, const float* feat, const int64_t* 
                          float w_tri, float margin, const float* upstream, float* loss, float* dlogits, float* gram, int* pidx, int* nidx,
                          float* coef, float* dfeat, hipStream_t st) {
     SIG_CHECK_ARG(logits && feat && target && loss && gram && pidx && nidx && coef, "reid_loss: null pointer");
-    SIG_CHECK_ARG(B > 1 && B <= 128 && (F & 3) == 0, "reid_loss: batch %d must be in 2..128", B);
+    SIG_CHECK_ARG(B > 1 && B <= 128 && (F & 3) == 0 && F <= 2048, "reid_loss: batch %d must be in 2..128, features %d <= 2048", B, F);
     // ce_ls parks its per-row loss terms in coef[2a]; triplet_mine (always launched) reads them, then rewrites coef
     hipLaunchKernelGGL(ce_ls_kernel, dim3(B), dim3(256), 0, st, logits, target, B, C, eps, upstream, w_id, coef, dlogits);
     SIG_CHECK_LAUNCH("ce_ls");

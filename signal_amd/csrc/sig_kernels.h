@@ -98,13 +98,15 @@ int sig_launch_gam_bwd(const float* fh, const float* nrm, const float* coef, con
                        float* dtemp, hipStream_t st);
 int sig_launch_lam_gather(const float* tokens, int B, int L, bf16_t* xb, size_t xstride, int dt, hipStream_t st);
 int sig_launch_lam_scatter_add(const float* src, int m, int B, int L, float* dtokens, hipStream_t st);
-int sig_launch_lam_tail_fwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const float* wd,
-                            const float* bd, const float* w4, float* a2pre, float* offs, float* samp, int dt, hipStream_t st);
+// per-modality parameter / gradient pointers of the DAS tails (DAS_r, DAS_n, DAS_t); passed by value to the kernels
+struct SigLamTailPtrs { const float *wd[3], *bd[3], *w4[3]; float *dwd[3], *dbd[3], *dw4[3]; };
+// all three modalities in one launch (grid (B, 3)); a_stride = elements between the modalities' [Rp, 512] activation blocks
+int sig_launch_lam_tail_fwd(const float* tokens, int B, int L, int h, int w, const bf16_t* a1, size_t a_stride, const SigLamTailPtrs& tp,
+                            float* a2pre, float* offs, float* samp, int dt, hipStream_t st);
 int sig_launch_lam_loss(const float* samp, size_t n, float* loss, hipStream_t st);
-int sig_launch_lam_tail_bwd(const float* tokens, int m, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre,
-                            const float* wd, const float* w4, const float* a2pre, const float* offs, const float* samp_all,
-                            size_t nsamp, const float* dloss, bf16_t* da1pre, float* dwd, float* dbd, float* dw4, float* dtokens,
-                            int dt, hipStream_t st, float* partials = nullptr);
+int sig_launch_lam_tail_bwd(const float* tokens, int B, int L, int h, int w, const bf16_t* a1, const bf16_t* a1pre, size_t a_stride,
+                            const SigLamTailPtrs& tp, const float* a2pre, const float* offs, const float* samp_all, size_t nsamp,
+                            const float* dloss, bf16_t* da1pre, float* dtokens, int dt, hipStream_t st, float* partials = nullptr);
 
 // ---- optimizer (optim.hip) ------------------------------------------------------------------------------
 int sig_launch_adam(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, const int* seg_end, const float* seg_lr,

@@ -256,6 +256,15 @@ int sig_gam_bwd(int B, int L, const SigGamActs* a, const float* dloss, float* dt
     return sig_launch_gam_bwd(a->fh, a->nrm, a->coef, dloss, B, L, dtokens, d_contra_temp, (hipStream_t)stream);
 }
 
+static SigLamTailPtrs lam_ptrs(const SigDasParams* p3, const SigDasGrads* g3) {
+    SigLamTailPtrs t;
+    for (int m = 0; m < 3; ++m) {
+        t.wd[m] = p3[m].wd; t.bd[m] = p3[m].bd; t.w4[m] = p3[m].w4;
+        t.dwd[m] = g3 ? g3[m].wd : nullptr; t.dbd[m] = g3 ? g3[m].bd : nullptr; t.dw4[m] = g3 ? g3[m].w4 : nullptr;
+    }
+    return t;
+}
+
 int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, int dtype, const SigDasParams* p3, const SigLamActs* a, void* stream) {
     SIG_CHECK_ARG(tokens && p3 && a, "lam_fwd: null argument");
     SIG_CHECK_ARG(a->xb && a->q && a->a1 && a->a1pre && a->a2pre && a->offs && a->samp && a->loss, "lam_fwd: activation buffer missing");
@@ -269,9 +278,9 @@ int sig_lam_fwd(const float* tokens, int B, int L, int h, int w, int dtype, cons
         RUN(sig_launch_gemm_nt(nt(dt, a->xb + o, d, p->w_q, d, R, d, d, a->q + o, d, p->b_q), SIG_EPI_BIAS_BF16, st));
         RUN(sig_launch_gemm_nt(nt(dt, a->q + o, d, p->w_0, d, R, d, d, a->a1 + o, d, p->b_0, nullptr, 0, a->a1pre + o, d),
                                SIG_EPI_BIAS_GELUERF_BF16, st));
-        RUN(sig_launch_lam_tail_fwd(tokens, m, B, L, h, w, a->a1 + o, p->wd, p->bd, p->w4, a->a2pre + (size_t)m * B * P * d,
-                                    a->offs + (size_t)m * B * P * 3, a->samp + (size_t)m * B * P * d, dt, st));
     }
+    // the three modalities' tails (depthwise conv, offsets, bilinear sampling) in ONE launch
+    RUN(sig_launch_lam_tail_fwd(tokens, B, L, h, w, a->a1, (size_t)Rp * d, lam_ptrs(p3, nullptr), a->a2pre, a->offs, a->samp, dt, st));
     RUN(sig_launch_lam_loss(a->samp, (size_t)B * P * d, a->loss, st));
     return 0;
 }
@@ -284,18 +293,20 @@ int sig_lam_bwd(const float* tokens, int B, int L, int h, int w, int dtype, cons
     const int dt = dtype;
     const int R = B * (L - 1), Rp = pad128(R), d = 512, P = (h / 4) * (w / 4);
     const size_t nsamp = (size_t)B * P * d;
+    for (int m = 0; m < 3; ++m) SIG_CHECK_ARG(p3[m].wt_q && p3[m].wt_0, "lam_bwd: transposed weights missing");
+    // all three tails first (one launch + one reduce): da1pre [3][Rp,512]; the per-sample partial rows of the tail's
+    // parameter gradients live in dx, which is free until the first proj_q dgrad below
+    RUN(sig_launch_lam_tail_bwd(tokens, B, L, h, w, a->a1, a->a1pre, (size_t)Rp * d, lam_ptrs(p3, g3), a->a2pre, a->offs, a->samp, nsamp,
+                                dloss, s->da1pre, dtokens, dt, st, (size_t)3 * B * 18 * d <= (size_t)Rp * d ? s->dx : nullptr));
     for (int m = 0; m < 3; ++m) {
         const SigDasParams* p = p3 + m;
         const SigDasGrads* g = g3 + m;
-        SIG_CHECK_ARG(p->wt_q && p->wt_0, "lam_bwd: transposed weights missing");
         const size_t o = (size_t)m * Rp * d;
-        RUN(sig_launch_lam_tail_bwd(tokens, m, B, L, h, w, a->a1 + o, a->a1pre + o, p->wd, p->w4, a->a2pre + (size_t)m * nsamp,
-                                    a->offs + (size_t)m * B * P * 3, a->samp, nsamp, dloss, s->da1pre, g->wd, g->bd, g->w4, dtokens, dt, st,
-                                    (size_t)B * 18 * d <= (size_t)Rp * d ? s->dx : nullptr));   // dx is free until the proj_q dgrad below
+        const bf16_t* da1 = s->da1pre + o;
         // conv_offset.0
-        RUN(sig_launch_gemm_nt(nt(dt, s->da1pre, d, p->wt_0, d, R, d, d, s->dq, d), SIG_EPI_BF16, st));
-        RUN(sig_launch_gemm_tn(tn(dt, s->da1pre, d, a->q + o, d, Rp, d, d, g->w_0, d), st));
-        RUN(sig_launch_colsum_bf16(s->da1pre, d, R, d, g->b_0, dt, st));
+        RUN(sig_launch_gemm_nt(nt(dt, da1, d, p->wt_0, d, R, d, d, s->dq, d), SIG_EPI_BF16, st));
+        RUN(sig_launch_gemm_tn(tn(dt, da1, d, a->q + o, d, Rp, d, d, g->w_0, d), st));
+        RUN(sig_launch_colsum_bf16(da1, d, R, d, g->b_0, dt, st));
         // proj_q
         RUN(sig_launch_gemm_nt(nt(dt, s->dq, d, p->wt_q, d, R, d, d, s->dx, d), SIG_EPI_F32, st));
         RUN(sig_launch_gemm_tn(tn(dt, s->dq, d, a->xb + o, d, Rp, d, d, g->w_q, d), st));

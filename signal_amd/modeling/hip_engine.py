@@ -502,7 +502,7 @@ class HipPath:
                      a2pre=w.v(3 * B * P * 512), offs=w.v(3 * B * P * 3), samp=w.v(3 * B * P * 512), loss=w.v(1 + 64))
             ws = {"B": B, "train": train, "t": t, "acts": fill(_lib.SigLamActs, **t)}
             if train:
-                s = dict(da1pre=w.z(R, 512, BF), dq=w.z(R, 512, BF), dx=w.z(R, 512))
+                s = dict(da1pre=w.z(3 * Rp, 512, BF), dq=w.z(R, 512, BF), dx=w.z(R, 512))
                 ws["s"], ws["scratch"] = s, fill(_lib.SigLamScratch, **s)
             return ws
         ws = self._get_ws(self._lam_ws, (B, train), make)

@@ -52,3 +52,11 @@ y2, m2, r2 = y.clone(), mean.clone(), rstd.clone()
 dx = torch.zeros(M, 768, device=dev); dxb = torch.zeros(M, 768, device=dev, dtype=torch.bfloat16)
 dy = mk(M, 768); dres = torch.randn(M, 768, device=dev)
 check("layernorm_bwd (dx only)", lambda: ops.layernorm_bwd(dy, x, g, m2, r2, M, dres=dres, dx_f32=dx, dx_bf16=dxb), [dx, dxb])
+dg, db = torch.zeros(768, device=dev), torch.zeros(768, device=dev)
+check("layernorm_bwd (+ dgamma/dbeta, partial rows + reduce)", lambda: ops.layernorm_bwd(dy, x, g, m2, r2, M, dres=dres, dx_f32=dx, dx_bf16=dxb, dgamma=dg, dbeta=db), [dx, dxb, dg, db])
+# fp16 operands through the same kernels (template instantiations of their own)
+ah, wh = torch.randn(Mp, 768, device=dev).half(), (torch.randn(3072, 768, device=dev) * 0.02).half()
+uh, oh = torch.randn(Mp, 3072, device=dev).half(), torch.zeros(Mp, 3072, device=dev, dtype=torch.float16)
+check("nt c_proj dgrad (256, DGELU, fp16)", lambda: ops.gemm_nt(ah, wh, M, ops.DGELU_BF16, oh, aux=uh), [oh])
+ph, qh = torch.randn(Mp, 3072, device=dev).half(), torch.randn(Mp, 768, device=dev).half(); outh = torch.zeros(3072, 768, device=dev)
+check("tn c_fc wgrad (256x16, fp16)", lambda: ops.gemm_tn(ph, qh, outh), [outh])
