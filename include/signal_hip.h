@@ -47,9 +47,11 @@ enum {
     SIG_GEMM_BIAS_F32 = 2,      /* out f32  = acc + bias                            */
     SIG_GEMM_BIAS_BF16 = 3,     /* out bf16 = acc + bias                            */
     SIG_GEMM_BIAS_RES_F32 = 4,  /* out f32  = acc + bias + res  (res may alias out) */
-    SIG_GEMM_BIAS_GELU_BF16 = 5,/* aux bf16 = acc + bias (if aux), out bf16 = QuickGELU(acc + bias) */
-    SIG_GEMM_DGELU_BF16 = 6,    /* out bf16 = acc * QuickGELU'(aux)                 */
-    SIG_GEMM_BIAS_GELUERF_BF16 = 7, /* as 5 with the exact-erf GELU (nn.GELU(), useA.py:356, DAS.py:59) */
+    SIG_GEMM_BIAS_GELU_BF16 = 5,/* out 16-bit = QuickGELU(acc + bias); aux 16-bit (if given) = QuickGELU'(acc + bias),
+                                   the only thing backward needs of the pre-activation             */
+    SIG_GEMM_DGELU_BF16 = 6,    /* out 16-bit = acc * aux  (aux = the derivative saved by 5)         */
+    SIG_GEMM_BIAS_GELUERF_BF16 = 7, /* exact-erf GELU (nn.GELU(), useA.py:356, DAS.py:59): out = GELU(acc + bias),
+                                   aux (if given) = the pre-activation acc + bias                  */
     SIG_GEMM_DGELUERF_BF16 = 8, /* out bf16 = acc * GELU_erf'(aux)                  */
     SIG_GEMM_RES_F32 = 9        /* out f32  = acc + res                             */
 };
@@ -155,8 +157,8 @@ typedef struct SigBlockActs {
     uint16_t* attn;                    /* bf16 [Mp,D] */
     float* x_mid;                      /* f32 [Mp,D] */
     uint16_t* h2;  float *mean2, *rstd2;
-    uint16_t* u;                       /* bf16 [Mp,F] pre-activation (NULL when no backward is needed) */
-    uint16_t* g;                       /* bf16 [Mp,F] QuickGELU(u) */
+    uint16_t* u;                       /* 16-bit [Mp,F] QuickGELU'(c_fc pre-activation) (NULL when no backward is needed) */
+    uint16_t* g;                       /* 16-bit [Mp,F] QuickGELU(c_fc pre-activation) */
     float* x_out;                      /* f32 [Mp,D] block output (written) */
 } SigBlockActs;
 typedef struct SigBlockGrads {

@@ -114,7 +114,9 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
 #pragma unroll
     for (int j = 0; j < TN; ++j) csum[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bool save_u = GELU_FWD && p.aux != nullptr;
-    const bool do_sum = p.colsum != nullptr;
+    // column sums (bias gradients) are a by-product of backward GEMMs: the 16-bit forward epilogues carry no code for them
+    constexpr bool CAN_SUM = EPI != SIG_EPI_BIAS_BF16 && !GELU_FWD;
+    const bool do_sum = CAN_SUM && p.colsum != nullptr;
     const __amdgpu_buffer_rsrc_t r_out = out_rsrc(p.out), r_aux = out_rsrc(p.aux);
     // GELU': the whole tile's saved pre-activations are requested before anything is consumed (TM*TN/2 16-B loads per
     // lane, in the registers the operand fragments no longer need) -- inside the store loop their latency was exposed
@@ -130,10 +132,14 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
                 uq[i][jp] = *(const uint4*)((const bf16_t*)p.aux + (size_t)(m < p.M ? m : 0) * p.ldaux + ns + jp * 32);
         }
     }
+    // FULL: every row of this wave's tile is < M (all tiles but the last row of tiles): no exec masking around the stores,
+    // no per-row selects in the column sums
+    auto rows = [&](auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m_base + i * 16 + fr;
-        const bool live = m < p.M;
+        const bool live = FULL || m < p.M;
         uint32_t pk[TN][2], pu[TN][2];
         if (GELU_BWD) {
 #pragma unroll
@@ -157,17 +163,35 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
             f32x4_t x = acc[i][j] + bias4[j];
             if (HAS_RES && live) x += *(const f32x4_t*)(p.res + (size_t)m * p.ldr + nc + j * 16);
             if (GELU_FWD) {
-                pu[j][0] = pack2_t<DT>(x[0], x[1]);
-                pu[j][1] = pack2_t<DT>(x[2], x[3]);
+                if constexpr (QUICK) {
+                    // what backward needs of the pre-activation is only QuickGELU'(u): it is saved INSTEAD of u (16-bit
+                    // either way), so the GELU' dgrad epilogue is one multiply per element instead of exp + rcp + 5
+                    f32x4_t sg, t = x * -2.4554669595930156f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = QUICK ? quick_gelu_f(x[e]) : gelu_erf_f(x[e]);
+                    for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+                    t += 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sg[e] = __builtin_amdgcn_rcpf(t[e]);
+                    if (save_u) {
+                        const f32x4_t a = x * 1.702f;
+                        const f32x4_t d = sg + sg * (a - a * sg);          // s (1 + 1.702 u (1 - s))
+                        pu[j][0] = pack2_t<DT>(d[0], d[1]);
+                        pu[j][1] = pack2_t<DT>(d[2], d[3]);
+                    }
+                    x *= sg;
+                } else {
+                    pu[j][0] = pack2_t<DT>(x[0], x[1]);
+                    pu[j][1] = pack2_t<DT>(x[2], x[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = gelu_erf_f(x[e]);
+                }
             }
             if (GELU_BWD) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t w = pu[j][e >> 1];
                     const float u = cvt16f_t<DT>((bf16_t)((e & 1) ? (w >> 16) : (w & 0xffff)));
-                    x[e] *= QUICK ? quick_gelu_grad_f(u) : gelu_erf_grad_f(u);
+                    x[e] *= QUICK ? u : gelu_erf_grad_f(u);                 // QUICK: aux already holds QuickGELU'(u)
                 }
             }
             if (OUT_F32) {
@@ -188,19 +212,24 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
                                    make_uint4(pk[2 * jp][0], pk[2 * jp][1], pk[2 * jp + 1][0], pk[2 * jp + 1][1]));
             }
         }
-        if (GELU_FWD) {
+        if (GELU_FWD && save_u) {
 #pragma unroll
             for (int jp = 0; jp < TN / 2; ++jp) {
                 lane_swap16(pu[2 * jp][0], pu[2 * jp + 1][0]);
                 lane_swap16(pu[2 * jp][1], pu[2 * jp + 1][1]);
-                if (live && save_u)
+                if (live)
                     store16_policy<store_aux<EPI>()>(r_aux, p.aux, ((size_t)m * p.ldaux + ns + jp * 32) * 2,
                                    make_uint4(pu[2 * jp][0], pu[2 * jp][1], pu[2 * jp + 1][0], pu[2 * jp + 1][1]));
             }
         }
     }
+    };
+    // (two copies of the row loop cost registers: the residual / GELU-forward epilogues spill with both, so only the
+    // GELU' dgrad -- whose remaining work is the column-sum selects -- gets the split)
+    if (EPI == SIG_EPI_DGELU_BF16 && m_base + TM * 16 <= p.M) rows(std::true_type{});
+    else rows(std::false_type{});
     // optional bias-gradient by-product: column sums of what was just written
-    if (p.colsum) {
+    if (do_sum) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -735,6 +764,8 @@ static int dispatch_nt(const SigGemmNT& p, int epi, hipStream_t st) {
     SIG_CHECK_ARG((p.lda & 7) == 0 && (p.ldb & 7) == 0 && (p.ldo & 7) == 0, "gemm_nt: leading dims must keep 16-B alignment");
     SIG_CHECK_ARG(p.lda >= p.K && p.ldb >= p.K && p.ldo >= p.N, "gemm_nt: leading dimension smaller than the row");
     SIG_CHECK_ARG(p.A && p.Bt && p.out, "gemm_nt: null operand");
+    SIG_CHECK_ARG(!p.colsum || !(epi == SIG_EPI_BIAS_BF16 || epi == SIG_EPI_BIAS_GELU_BF16 || epi == SIG_EPI_BIAS_GELUERF_BF16),
+                  "gemm_nt: the 16-bit forward epilogues (%d) carry no column sums", epi);
     switch (epi) {
         case SIG_EPI_F32: return launch_nt<SIG_EPI_F32, DT>(p, st);
         case SIG_EPI_BF16: return launch_nt<SIG_EPI_BF16, DT>(p, st);

@@ -9,8 +9,8 @@ enum SigEpilogue {
     SIG_EPI_BIAS_F32 = 2,       // out f32 = acc + bias
     SIG_EPI_BIAS_BF16 = 3,      // out bf16 = acc + bias
     SIG_EPI_BIAS_RES_F32 = 4,   // out f32 = acc + bias + res   (res may alias out)
-    SIG_EPI_BIAS_GELU_BF16 = 5, // aux bf16 = acc + bias (if aux), out bf16 = QuickGELU(acc + bias)
-    SIG_EPI_DGELU_BF16 = 6,     // out bf16 = acc * QuickGELU'(aux)
+    SIG_EPI_BIAS_GELU_BF16 = 5, // out 16-bit = QuickGELU(acc + bias), aux 16-bit = QuickGELU'(acc + bias) (if aux)
+    SIG_EPI_DGELU_BF16 = 6,     // out 16-bit = acc * aux
     SIG_EPI_BIAS_GELUERF_BF16 = 7, // aux bf16 = acc + bias (if aux), out bf16 = GELU_erf(acc + bias)
     SIG_EPI_DGELUERF_BF16 = 8,  // out bf16 = acc * GELU_erf'(aux)
     SIG_EPI_RES_F32 = 9,        // out f32 = acc + res

@@ -122,7 +122,7 @@ int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
     // column sums of dx_out, which the stage ABOVE accumulates when it writes dx_out (b_proj_done) -- else a pass here.
     // ---- MLP ----
     RUN(sig_launch_gemm_nt(with_colsum(nt(dt, dx_out_b, D, p->wt_proj, D, M, F, D, s->du, F, nullptr, nullptr, 0, a->u, F), g->b_fc),
-                           SIG_EPI_DGELU_BF16, st));                                              // du = (dx_out W_proj) * QuickGELU'(u)
+                           SIG_EPI_DGELU_BF16, st));                                              // du = (dx_out W_proj) * QuickGELU'(pre-act), saved by c_fc
     RUN(sig_launch_gemm_tn(tn(dt, dx_out_b, D, a->g, F, Mp, D, F, g->w_proj, F), st));
     if (!b_proj_done) RUN(sig_launch_colsum_bf16(dx_out_b, D, M, D, g->b_proj, dt, st));
     RUN(sig_launch_gemm_nt(nt(dt, s->du, F, p->wt_fc, F, M, D, F, s->dh, D), SIG_EPI_BF16, st));     // dh2 = du W_fc

@@ -18,7 +18,7 @@ _lib.LIB_PATH = lib
 _lib._lib = None
 L = _lib.load()
 dev = torch.device("cuda:0")
-M = 24768; Mp = ops.pad_rows(M)
+M = int(os.environ.get('STAMP_M', '24768')); Mp = ops.pad_rows(M)   # STAMP_M=512: a few tiles only -> a tile's cost with the chip idle
 for name, n, k, epi in [("qkv", 2304, 768, ops.BIAS_BF16), ("c_fc", 3072, 768, ops.BIAS_GELU_BF16), ("c_fc_inf", 3072, 768, ops.BIAS_GELU_BF16),
                         ("dgelu", 3072, 768, ops.DGELU_BF16), ("c_proj", 768, 3072, ops.BIAS_RES_F32)]:
     a = torch.randn(Mp, k, device=dev).to(torch.bfloat16); w = (torch.randn(n, k, device=dev) * .02).to(torch.bfloat16)
