@@ -39,6 +39,9 @@ int sig_version(void);
 #define SIG_PROF_TN256 100
 int sig_prof_begin(int epilogue, int N, int K, int max_launches);
 int sig_prof_end(double* total_ms, int* launches, double* flops);
+/* Tuning / test aid: pin the row tile of sig_gemm_nt (128, 256 or 320; 0 = choose by the cost estimate) wherever that
+ * kernel is legal for the shape; returns the previous setting.  Same as the environment variable SIG_GEMM_TILE. */
+int sig_tune_gemm_tile(int tile);
 
 /* ---- epilogues of sig_gemm_nt ---------------------------------------------------------------- */
 enum {

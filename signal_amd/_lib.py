@@ -11,10 +11,13 @@ LIB_PATH = os.environ.get("SIGNAL_HIP_LIB") or os.path.join(_HERE, "lib", "libsi
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
+_TUNING_ONLY = {"sig_tune_gemm_tile"}
+
 # name -> argtypes; mirrors include/signal_hip.h one to one (tests check the export list against the header)
 SIGNATURES = {
     "sig_prof_begin": [_i, _i, _i, _i],
     "sig_prof_end": [_vp, _vp, _vp],
+    "sig_tune_gemm_tile": [_i],
     "sig_gemm_nt": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "sig_gemm_tn": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "sig_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
@@ -142,6 +145,8 @@ def load():
     lib.sig_version.restype = _i
     lib.sig_version.argtypes = []
     for name, argtypes in SIGNATURES.items():
+        if name in _TUNING_ONLY and not hasattr(lib, name):
+            continue          # an older build loaded through SIGNAL_HIP_LIB for an A/B run
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _i

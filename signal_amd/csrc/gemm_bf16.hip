@@ -244,6 +244,94 @@ __device__ __forceinline__ void epilogue_regs(const SigGemmNT& p, f32x4_t (&acc)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register epilogue in the NATURAL MFMA orientation (D = A-fragment x B-fragment): lane (fr, g) holds, for 16-row group i
+// and MFMA column group j, rows i*16 + 4g + e (e = 0..3) of B-slot fr.  The kernel stages the B operand so that slot fr
+// of group j is output column 4 fr + j of the wave's 64-column strip (a row permutation of the LDS image, free: it is the
+// per-lane source address of the LDS-DMA): the 4 accumulators {acc[i][0..3][e]} of a lane are then 4 CONSECUTIVE columns
+// of one row, and the 16 lanes fr = 0..15 of a 16-lane row cover 64 consecutive columns.  One store instruction writes
+// 4 rows x (256 B of f32 | 128 B of 16-bit) with consecutive lanes on consecutive addresses: whole cache lines per
+// quarter-wave, no lane exchange, no LDS.  Why it matters (tools/micro/store_tail.hip, one 128-KB tile alone on the chip):
+// a CU drains lane-consecutive whole lines at 50 B/clk (27 B/clk with 8-B lanes) but only 13.7 B/clk when the lanes of a
+// line are scattered over the wave, as in the swapped-operand layout above (16 rows x 64 B per instruction).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int TM, int DT>
+__device__ __forceinline__ void epilogue_nat(const SigGemmNT& p, f32x4_t (&acc)[TM][4], int m_base, int n_base, int lane) {
+    constexpr bool HAS_BIAS = EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_F32 || EPI == SIG_EPI_BIAS_RES_F32 ||
+                              EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16;
+    constexpr bool HAS_RES = EPI == SIG_EPI_BIAS_RES_F32 || EPI == SIG_EPI_RES_F32;
+    constexpr bool OUT_F32 = EPI == SIG_EPI_F32 || EPI == SIG_EPI_BIAS_F32 || HAS_RES;
+    constexpr bool GELU_FWD = EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16;
+    constexpr bool GELU_BWD = EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_DGELUERF_BF16;
+    constexpr bool QUICK = EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_DGELU_BF16;
+    constexpr bool CAN_SUM = EPI != SIG_EPI_BIAS_BF16 && !GELU_FWD;
+    const int fr = lane & 15, g = lane >> 4;
+    const int n = n_base + fr * 4;                               // this lane's 4 columns
+    const f32x4_t bias4 = HAS_BIAS ? *(const f32x4_t*)(p.bias + n) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool save_u = GELU_FWD && p.aux != nullptr;
+    const bool do_sum = CAN_SUM && p.colsum != nullptr;
+    f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        uint2 uq[4];
+        if (GELU_BWD) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m_base + i * 16 + g * 4 + e;
+                uq[e] = *(const uint2*)((const bf16_t*)p.aux + (size_t)(m < p.M ? m : 0) * p.ldaux + n);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m_base + i * 16 + g * 4 + e;
+            const bool live = m < p.M;
+            f32x4_t x = (f32x4_t){acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]} + bias4;
+            if (HAS_RES && live) x += *(const f32x4_t*)(p.res + (size_t)m * p.ldr + n);
+            if (GELU_FWD) {
+                f32x4_t keep = x;
+                if constexpr (QUICK) {
+                    f32x4_t sg, t = x * -2.4554669595930156f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = __builtin_amdgcn_exp2f(t[c]);
+                    t += 1.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sg[c] = __builtin_amdgcn_rcpf(t[c]);
+                    const f32x4_t a = x * 1.702f;
+                    keep = sg + sg * (a - a * sg);                // QuickGELU'(pre): what backward needs (see epilogue_regs)
+                    x *= sg;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = gelu_erf_f(x[c]);
+                }
+                if (save_u && live)
+                    *(uint2*)((bf16_t*)p.aux + (size_t)m * p.ldaux + n) = make_uint2(pack2_t<DT>(keep[0], keep[1]), pack2_t<DT>(keep[2], keep[3]));
+            }
+            if (GELU_BWD) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t w = c < 2 ? uq[e].x : uq[e].y;
+                    const float u = cvt16f_t<DT>((bf16_t)((c & 1) ? (w >> 16) : (w & 0xffff)));
+                    x[c] *= QUICK ? u : gelu_erf_grad_f(u);
+                }
+            }
+            if (live) {
+                if (OUT_F32) *(f32x4_t*)((float*)p.out + (size_t)m * p.ldo + n) = x;
+                else *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = make_uint2(pack2_t<DT>(x[0], x[1]), pack2_t<DT>(x[2], x[3]));   // plain: sc1 on these 8-B stores measured qkv 92 -> 105 us
+            }
+            if (do_sum && live) csum += x;
+        }
+    }
+    if (do_sum) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float t = csum[c];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (g == 0) atomicAdd(p.colsum + n + c, t);
+        }
+    }
+}
+
 #ifdef SIG_GEMM_STAMPS   // diagnostic build only (tools/gemm_stamps.py): where does a tile's time go?
 __device__ unsigned long long g_stamps[5 * 8192];
 extern "C" int sig_debug_read_stamps(unsigned long long* out, int nblocks) {
@@ -646,6 +734,172 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(SigGemmNT p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT, 320 x 256 tile: the phase pipeline of gemm_nt256_kernel with 10 x 4 MFMA tiles per wave (8 waves x 160 x 64), for
+// the 768-column GEMMs (out_proj, c_proj and every N = 768 dgrad): at M = 24768 they are 78 x 3 = 234 tiles = ONE round
+// of the 256 CUs, where 160x128 tiles need two rounds of a simpler, less efficient loop (68 % of the MFMA issue rate
+// against 83 %).  LDS 2 x 72 KB, one block per CU; a K-step is 4 phases of 20 MFMAs, 28 fragment reads per 80 MFMAs.
+//     P0: MFMA(k0, rows lo)   read A(k0,hi)              DMA B0..B3 of the next stage
+//     P1: MFMA(k0, rows hi)   read A(k1,lo), B(k1)
+//     P2: MFMA(k1, rows lo)   read A(k1,hi)
+//     -- s_waitcnt vmcnt(0) lgkmcnt(0); barrier --
+//     P3: MFMA(k1, rows hi)   read A'(k0,lo), B'(k0) from the NEXT stage      DMA A0..A4 of the stage after
+// The last row tile reaches past the 128-row padding of the operand buffers: its DMA rows are clamped to the last
+// padded row (never stored: the epilogue is row-predicated).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int DT>
+__global__ __launch_bounds__(512, 2) void gemm_nt320_kernel(SigGemmNT p, int mp) {
+    constexpr int BM = 320, BN = 256, STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = p.N >> 8, tm = gridDim.x / tn, wb = p.band;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int per = tm * wb, bnd = id / per, rr = id - bnd * per;
+    const int tile_m = rr / wb, tile_n = bnd * wb + (rr - tile_m * wb);
+    const int m0 = tile_m * BM, n0 = tile_n << 8;
+
+    // DMA pieces (8 rows x 128 B): A 40 = 5 per wave, B 32 = 4 per wave
+    unsigned ao[5], bo[4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = (wave * 5 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int rc = m0 + r < mp ? r : mp - 1 - m0;                 // clamp (last row tile only)
+        ao[j] = (unsigned)(rc * p.lda + c * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);             // row of the LDS image
+        // ... which holds weight row (= output column) 4 * slot + group of its 64-row strip: epilogue_nat's layout
+        const int sr = (r & ~63) + 4 * (r & 15) + ((r >> 4) & 3);
+        bo[j] = (unsigned)(sr * p.ldb + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2u;
+    }
+    const bf16_t* abase = p.A + (size_t)m0 * p.lda;
+    const bf16_t* bbase = p.Bt + (size_t)n0 * p.ldb;
+    auto dma_a = [&](int j, int kt, int stage) { glds16_untracked_s(abase + kt * 64, ao[j], smem + stage * STAGE + (wave * 5 + j) * 1024); };
+    auto dma_b = [&](int j, int kt, int stage) { glds16_untracked_s(bbase + kt * 64, bo[j], smem + stage * STAGE + BM * 128 + (wave * 4 + j) * 1024); };
+
+    const int fr = lane & 15, g = lane >> 4, sw = fr >> 1;
+    const int wm = (wave >> 2) * 160, wn = (wave & 3) * 64;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ch = (((ks << 2) | g) ^ sw) << 4;
+        aoff[ks] = (wm + fr) * 128 + ch;
+        boff[ks] = BM * 128 + (wn + fr) * 128 + ch;
+    }
+    bf16x8_t aX[5], aY[5], bX[4], bY[4];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto rd_a = [&](int stage, int ks, auto half_c, bf16x8_t (&a)[5]) {
+        constexpr int H = decltype(half_c)::value;
+        const unsigned ad = lds0 + stage * STAGE + aoff[ks];
+        SIG_RD128(a[0], ad, (H * 5 + 0) * 2048);
+        SIG_RD128(a[1], ad, (H * 5 + 1) * 2048);
+        SIG_RD128(a[2], ad, (H * 5 + 2) * 2048);
+        SIG_RD128(a[3], ad, (H * 5 + 3) * 2048);
+        SIG_RD128(a[4], ad, (H * 5 + 4) * 2048);
+    };
+    auto rd_b = [&](int stage, int ks, bf16x8_t (&b)[4]) {
+        const unsigned ad = lds0 + stage * STAGE + boff[ks];
+        SIG_RD128(b[0], ad, 0);
+        SIG_RD128(b[1], ad, 2048);
+        SIG_RD128(b[2], ad, 4096);
+        SIG_RD128(b[3], ad, 6144);
+    };
+#define SIG_WAIT5(n, a) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]))
+#define SIG_WAIT9(n, a, b)                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), \
+                 "+v"(b[1]), "+v"(b[2]), "+v"(b[3]))
+    f32x4_t acc[10][4];
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int half, const bf16x8_t (&a)[5], const bf16x8_t (&b)[4]) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[half * 5 + i][j] = mfma16<DT>(a[i], b[j], acc[half * 5 + i][j]);      // natural orientation: rows = A slots
+    };
+
+    const int nk = p.K >> 6;
+#ifdef SIG_GEMM_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    SIG_STAMP(ts0);
+#endif
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dma_a(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_b(j, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#ifdef SIG_GEMM_STAMPS
+    SIG_STAMP(ts1);
+#endif
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    rd_a(0, 0, H0{}, aX);
+    rd_b(0, 0, bX);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dma_a(j, 1, 1);
+    // lgkmcnt(n): everything but the newest n LDS reads has landed (in-order returns).  Needs nk >= 2.
+    auto step = [&](int kt, auto more_c, auto more2_c) {
+        constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+        const int st = kt & 1;
+        // P0: outstanding aX,bX (9) + aY (5)
+        rd_a(st, 0, H1{}, aY);
+        if (MORE) { dma_b(0, kt + 1, st ^ 1); dma_b(1, kt + 1, st ^ 1); dma_b(2, kt + 1, st ^ 1); dma_b(3, kt + 1, st ^ 1); }
+        SIG_WAIT9(5, aX, bX);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, aX, bX);
+        __builtin_amdgcn_sched_barrier(0);
+        // P1: outstanding aY (5) + aX,bY (9)
+        rd_a(st, 1, H0{}, aX);
+        rd_b(st, 1, bY);
+        SIG_WAIT5(9, aY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, aY, bX);
+        __builtin_amdgcn_sched_barrier(0);
+        // P2: outstanding aX,bY (9) + aY (5)
+        rd_a(st, 1, H1{}, aY);
+        SIG_WAIT9(5, aX, bY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, aX, bY);
+        __builtin_amdgcn_sched_barrier(0);
+        // stage boundary: this wave's DMA pieces of the next stage landed, all its reads of this stage returned
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(aY[0]), "+v"(aY[1]), "+v"(aY[2]), "+v"(aY[3]), "+v"(aY[4])::"memory");
+        __builtin_amdgcn_s_barrier();
+        // P3
+        if (MORE) {
+            rd_a(st ^ 1, 0, H0{}, aX);
+            rd_b(st ^ 1, 0, bX);
+        }
+        if (MORE2) { dma_a(0, kt + 2, st); dma_a(1, kt + 2, st); dma_a(2, kt + 2, st); dma_a(3, kt + 2, st); dma_a(4, kt + 2, st); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, aY, bY);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    for (int kt = 0; kt < nk - 2; ++kt) step(kt, T_{}, T_{});
+    step(nk - 2, T_{}, F_{});
+    step(nk - 1, F_{}, F_{});
+#ifdef SIG_GEMM_STAMPS
+    SIG_STAMP(ts2);
+#endif
+    epilogue_nat<EPI, 10, DT>(p, acc, m0 + wm, n0 + wn, lane);
+#ifdef SIG_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SIG_STAMP(ts3);
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_stamps[blockIdx.x * 4 + 0] = ts0; g_stamps[blockIdx.x * 4 + 1] = ts1;
+        g_stamps[blockIdx.x * 4 + 2] = ts2; g_stamps[blockIdx.x * 4 + 3] = ts3;
+    }
+#endif
+}
+
 // ---- live timing of one GEMM shape (bench.py's roofline leg): HIP events on the launch stream ----
 #include <vector>
 static struct {
@@ -699,11 +953,19 @@ static int choose_band(int tn, int K, int BN) {
     return 1;
 }
 
+// SIG_GEMM_TILE=<128|256|320> / sig_tune_gemm_tile(): pin the NT tile wherever that kernel is legal (tests, A/B runs)
+static int g_force_tile = -1;
+int sig_tune_gemm_tile_impl(int tile) {
+    const int prev = g_force_tile < 0 ? 0 : g_force_tile;
+    g_force_tile = tile;
+    return prev;
+}
+
 template <int EPI, int DT>
 static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     SigGemmNT p = p_in;
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("SIG_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    if (g_force_tile < 0) { const char* e = getenv("SIG_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
+    const int force = g_force_tile;
     // 256x256 phase-pipelined kernel when the problem fills the chip with it and the 128-row padding of the token
     // buffers happens to be a 256 multiple (M = 24768 -> 24832 = 97 * 256); otherwise the 128x128 kernel
     const int mp = ((p.M + 127) >> 7) << 7;
@@ -716,9 +978,40 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
         if (force_g < 0) { const char* e = getenv("SIG_GEMM_TILE_GELU"); force_g = e ? atoi(e) : 0; }
         if (force_g == 128) big = false;
     }
+    // 320x256 tiles (gemm_nt320_kernel): SIG_GEMM_TILE=320 wherever legal; by default where one CU-time estimate says so
+    const bool can320 = (p.N & 255) == 0 && p.K >= 128;
+    const int t320 = ((p.M + 319) / 320) * (p.N >> 8);
+    // One CU-time estimate per candidate: rounds of the chip x tile area / the MFMA issue share its main loop reaches
+    // (tools/gemm_stamps.py: 0.83 for the phase-pipelined 256- and 320-row kernels, 0.68 for the 128 / 160-row one, two of
+    // whose blocks share a CU).  N = 768 at M = 24768: 1 round of 320x256 against 2 rounds of 160x128 (measured 70 vs 80 us
+    // for the qkv dgrad, 90 vs 104 for c_fc's); qkv: 3 rounds against 4 of 256x256 (91 vs 94 us).  The GELU' dgrad keeps the
+    // 256x256 kernel (its saved derivative arrives by LDS-DMA under the main loop there).
+    bool tall320 = false;
+    if (can320 && EPI != SIG_EPI_DGELU_BF16 && EPI != SIG_EPI_DGELUERF_BF16) {
+        const int tm160 = (p.M + 159) / 160, t160 = tm160 * (p.N >> 7), t128 = (mp >> 7) * (p.N >> 7);
+        const float c320 = (float)((t320 + 255) / 256) * 81920.f / 0.83f;
+        const float c256 = big ? (float)(((mp >> 8) * (p.N >> 8) + 255) / 256) * 65536.f / 0.83f : 1e30f;
+        const float c160 = tm160 * 160 <= mp ? (float)((t160 + 511) / 512) * 40960.f / 0.68f : 1e30f;
+        const float c128 = (float)((t128 + 511) / 512) * 32768.f / 0.68f;
+        // a tie with 256x256 (c_fc: 4 rounds x 1.25 = 5 rounds) goes to the kernel whose epilogue suits the outputs: with the
+        // saved derivative as a second output the natural-orientation stores win (144 vs 153 us in the train step), with
+        // one output the 256x256 kernel does (128 vs 132 us at inference)
+        const bool two_out = (EPI == SIG_EPI_BIAS_GELU_BF16 || EPI == SIG_EPI_BIAS_GELUERF_BF16) && p.aux != nullptr;
+        tall320 = (c320 < c256 || (c320 == c256 && two_out)) && c320 < c160 && c320 < c128;
+    }
+    if (force == 320) tall320 = can320;
+    if (force != 0 && force != 320) tall320 = false;      // (SIG_GEMM_TILE=1: the choice without this kernel, for A/B runs)
     const bool timed = g_prof.on && g_prof.epi == EPI && g_prof.N == p.N && g_prof.K == p.K && g_prof.used + 2 <= g_prof.ev.size();
     if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-    if (big) {
+    if (tall320) {
+        static bool attr320 = false;
+        if (!attr320) {
+            (void)hipFuncSetAttribute((const void*)&gemm_nt320_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            attr320 = true;
+        }
+        p.band = choose_band(p.N >> 8, p.K, 256);
+        hipLaunchKernelGGL((gemm_nt320_kernel<EPI, DT>), dim3(t320), dim3(512), 147456, st, p, mp);
+    } else if (big) {
         static bool attr256 = false;
         if (!attr256) {
             (void)hipFuncSetAttribute((const void*)&gemm_nt256_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);

@@ -41,14 +41,25 @@ def padded(t, ops):
     return out
 
 
-# the last two select the 256x256 phase-pipelined kernel (>= 512 tiles; K = 128 is its shortest legal loop, the last row
-# tile is partial: 24768 = 96 * 256 + 192)
+# the last two reach the phase-pipelined 256x256 and 320x256 kernels on their own (>= 512 tiles; K = 128 is their shortest
+# legal loop, the last row tile is partial: 24768 = 96 * 256 + 192 = 77 * 320 + 128); the nt_tile fixture pins each kernel
+# on every shape it is legal for
 GEMM_SHAPES = [(774, 384, 128), (1000, 768, 3072), (4128, 2304, 768), (129, 128, 64), (2000, 512, 192), (24768, 1536, 128),
                (24768, 1536, 192)]
 
 
+@pytest.fixture(params=[0, 128, 256, 320], ids=lambda t: f"tile{t}")
+def nt_tile(request):
+    """Pins the NT row tile (0 = the launcher's own choice) so every kernel sees every epilogue and shape it is legal for."""
+    from signal_amd import _lib
+    lib = _lib.load()
+    prev = lib.sig_tune_gemm_tile(request.param)
+    yield request.param
+    lib.sig_tune_gemm_tile(prev)
+
+
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
-def test_gemm_nt_epilogues(dev, dt16, m, n, k):
+def test_gemm_nt_epilogues(dev, dt16, nt_tile, m, n, k):
     ops = _ops()
     T = tol_scale(dt16)
     bf = lambda t: t.to(dt16)
