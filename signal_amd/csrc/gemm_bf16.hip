@@ -1009,7 +1009,11 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)&gemm_nt320_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             attr320 = true;
         }
-        p.band = choose_band(p.N >> 8, p.K, 256);
+        // one round of the chip: every tile runs at once and the CUs walk k in step, so what an XCD's L2 shares is what its
+        // tiles have in common at the same k -- all column tiles of a row tile on one XCD read the A panel once (band =
+        // all columns: FETCH of the qkv dgrad 342 -> 114 MB of A; 70.5 -> 68 us, c_fc dgrad 91 -> 88.5); with several
+        // rounds the weight band that stays L2-resident while the rows sweep by matters instead (choose_band)
+        p.band = t320 <= 256 ? (p.N >> 8) : choose_band(p.N >> 8, p.K, 256);
         hipLaunchKernelGGL((gemm_nt320_kernel<EPI, DT>), dim3(t320), dim3(512), 147456, st, p, mp);
     } else if (big) {
         static bool attr256 = false;
