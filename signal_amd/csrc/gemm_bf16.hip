@@ -1565,18 +1565,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256x16_kernel(SigGemmTN p) {
 // holds rows i = wi + 16a + 4(lane >> 4) .. +3 of column j = wj + 16b + (lane & 15)
 __global__ __launch_bounds__(256) void tn_reduce16_kernel(const float* __restrict__ ws, float* __restrict__ out, int I, int J, int ldo,
                                                           int tiles, int split) {
+    // a block = the 4 column tiles b of one (wave, a): 16 rows x 64 columns of the output
+    __shared__ float tile[16][68];
     const int tj = J >> 8;
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index over all tiles
-    if (q >= (size_t)tiles * 16384) return;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index over all tiles (grid = tiles * 64 exactly)
     const int t = (int)(q >> 14), r = (int)(q & 16383);
     const int lane = r & 63, f = r >> 6, wave = f >> 5, a = (f >> 2) & 7, b = f & 3;
     const f32x4_t* src = (const f32x4_t*)(ws + (size_t)t * 65536) + r;
-    f32x4_t acc = *src;
-    for (int s = 1; s < split; ++s) acc += src[(size_t)s * tiles * 16384];
-    const int i = (t / tj) * 256 + (wave >> 2) * 128 + a * 16 + (lane >> 4) * 4;
-    const int j = (t % tj) * 256 + (wave & 3) * 64 + b * 16 + (lane & 15);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < split; s0 += 8) {          // 8 partial tiles requested before any is added (fixed order: deterministic)
+        f32x4_t v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) out[(size_t)(i + e) * ldo + j] += acc[e];
+        for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(s0 + k < split ? s0 + k : s0) * tiles * 16384];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < split) acc += v[k];
+    }
+    // fragment order -> rows: the read-modify-write of the output is then 16 B per lane on 256-B row segments instead of
+    // 4 B per lane (a dword store costs a store instruction's ~50 cycles for 256 B)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(lane >> 4) * 4 + e][b * 16 + (lane & 15)] = acc[e];
+    __syncthreads();
+    const int row = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+    const int i = (t / tj) * 256 + (wave >> 2) * 128 + a * 16 + row;
+    const int j = (t % tj) * 256 + (wave & 3) * 64 + c4;
+    float* o = out + (size_t)i * ldo + j;
+    const f32x4_t add = *(const f32x4_t*)&tile[row][c4];
+    if ((ldo & 3) == 0) {
+        *(f32x4_t*)o = *(const f32x4_t*)o + add;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += add[e];
+    }
 }
 
 // out[i][j] += sum over row chunks of the partial tiles written by gemm_tn256_kernel (unit = split * tiles + tile)

@@ -349,16 +349,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ a_
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int rbeg = blockIdx.x * 128 + wave * 32;
     if (c < N) {
-        for (int r = rbeg; r < rbeg + 32 && r < M; ++r) {
-            if (BF16) {
-                const uint4 u = *(const uint4*)((const bf16_t*)a_ + (size_t)r * lda + c);
-                acc[0] += cvt16f((bf16_t)(u.x & 0xffff), dt); acc[1] += cvt16f((bf16_t)(u.x >> 16), dt);
-                acc[2] += cvt16f((bf16_t)(u.y & 0xffff), dt); acc[3] += cvt16f((bf16_t)(u.y >> 16), dt);
-                acc[4] += cvt16f((bf16_t)(u.z & 0xffff), dt); acc[5] += cvt16f((bf16_t)(u.z >> 16), dt);
-                acc[6] += cvt16f((bf16_t)(u.w & 0xffff), dt); acc[7] += cvt16f((bf16_t)(u.w >> 16), dt);
-            } else {
-                const float4 v = *(const float4*)((const float*)a_ + (size_t)r * lda + c);
-                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        // 8 rows requested before any is consumed (a row-at-a-time loop left one 16-B load per lane in flight: 3.2 TB/s)
+        for (int r0 = rbeg; r0 < rbeg + 32 && r0 < M; r0 += 8) {
+            uint4 u[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0 + k < M ? r0 + k : M - 1;              // clamped rows are read but not added
+                u[k] = BF16 ? *(const uint4*)((const bf16_t*)a_ + (size_t)r * lda + c) : *(const uint4*)((const float*)a_ + (size_t)r * lda + c);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (r0 + k >= M) break;
+                if (BF16) {
+                    acc[0] += cvt16f((bf16_t)(u[k].x & 0xffff), dt); acc[1] += cvt16f((bf16_t)(u[k].x >> 16), dt);
+                    acc[2] += cvt16f((bf16_t)(u[k].y & 0xffff), dt); acc[3] += cvt16f((bf16_t)(u[k].y >> 16), dt);
+                    acc[4] += cvt16f((bf16_t)(u[k].z & 0xffff), dt); acc[5] += cvt16f((bf16_t)(u[k].z >> 16), dt);
+                    acc[6] += cvt16f((bf16_t)(u[k].w & 0xffff), dt); acc[7] += cvt16f((bf16_t)(u[k].w >> 16), dt);
+                } else {
+                    acc[0] += __uint_as_float(u[k].x); acc[1] += __uint_as_float(u[k].y);
+                    acc[2] += __uint_as_float(u[k].z); acc[3] += __uint_as_float(u[k].w);
+                }
             }
         }
     }
