@@ -179,6 +179,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
+            # RCCL's channel workgroups hold CUs while a bucket is in flight; the trainer sizes the backward GEMMs for
+            # 256 - SIGNAL_RESERVED_CUS free CUs (signal_amd/engine/trainer.py), so cap the channels at the same number
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("SIGNAL_RESERVED_CUS", "16"))
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")

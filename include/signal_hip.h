@@ -42,6 +42,10 @@ int sig_prof_end(double* total_ms, int* launches, double* flops);
 /* Tuning / test aid: pin the row tile of sig_gemm_nt (128, 256 or 320; 0 = choose by the cost estimate) wherever that
  * kernel is legal for the shape; returns the previous setting.  Same as the environment variable SIG_GEMM_TILE. */
 int sig_tune_gemm_tile(int tile);
+/* CUs (0..192) the GEMM launchers leave to concurrent work -- the RCCL channel workgroups that all-reduce gradient buckets
+ * under the backward pass (engine/processor.py:212-261 runs DDP's reducer there).  The one-block-per-CU kernels are sized
+ * in rounds of the FREE CUs; returns the previous setting.  Environment preset: SIG_RESERVED_CUS. */
+int sig_tune_reserved_cus(int n);
 
 /* ---- epilogues of sig_gemm_nt ---------------------------------------------------------------- */
 enum {

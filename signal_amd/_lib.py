@@ -11,13 +11,14 @@ LIB_PATH = os.environ.get("SIGNAL_HIP_LIB") or os.path.join(_HERE, "lib", "libsi
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
-_TUNING_ONLY = {"sig_tune_gemm_tile"}
+_TUNING_ONLY = {"sig_tune_gemm_tile", "sig_tune_reserved_cus"}
 
 # name -> argtypes; mirrors include/signal_hip.h one to one (tests check the export list against the header)
 SIGNATURES = {
     "sig_prof_begin": [_i, _i, _i, _i],
     "sig_prof_end": [_vp, _vp, _vp],
     "sig_tune_gemm_tile": [_i],
+    "sig_tune_reserved_cus": [_i],
     "sig_gemm_nt": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "sig_gemm_tn": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "sig_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],

@@ -953,6 +953,23 @@ static int choose_band(int tn, int K, int BN) {
     return 1;
 }
 
+// CUs the GEMM launchers may count on.  The big-tile kernels run ONE block per CU and are sized in rounds of the chip: a
+// 234-tile launch is one round on 256 free CUs and two as soon as 23 are taken.  While RCCL all-reduces gradient buckets
+// under the backward pass its channel workgroups hold CUs for milliseconds (a GEMM block's 8 waves x 256 registers cannot
+// share a CU with them), so the trainer reserves CUs for that phase (sig_tune_reserved_cus; SIG_RESERVED_CUS presets it)
+// and the tile choice and the wgrad's row split are made for the rest.
+static int g_reserved_cus = -1;
+static int free_cus() {
+    if (g_reserved_cus < 0) { const char* e = getenv("SIG_RESERVED_CUS"); g_reserved_cus = e ? atoi(e) : 0; }
+    const int f = 256 - g_reserved_cus;
+    return f < 64 ? 64 : f;
+}
+int sig_tune_reserved_cus_impl(int n) {
+    const int prev = g_reserved_cus < 0 ? 0 : g_reserved_cus;
+    g_reserved_cus = n < 0 ? 0 : (n > 192 ? 192 : n);
+    return prev;
+}
+
 // SIG_GEMM_TILE=<128|256|320> / sig_tune_gemm_tile(): pin the NT tile wherever that kernel is legal (tests, A/B runs)
 static int g_force_tile = -1;
 int sig_tune_gemm_tile_impl(int tile) {
@@ -970,7 +987,8 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     // buffers happens to be a 256 multiple (M = 24768 -> 24832 = 97 * 256); otherwise the 128x128 kernel
     const int mp = ((p.M + 127) >> 7) << 7;
     const bool can256 = (p.N & 255) == 0 && (mp & 255) == 0 && p.K >= 128;
-    bool big = can256 && (mp >> 8) * (p.N >> 8) >= 512;
+    const int cus = free_cus();
+    bool big = can256 && (mp >> 8) * (p.N >> 8) >= 2 * cus;
     if (force == 128) big = false;
     if (force == 256) big = can256;
     if (EPI == SIG_EPI_DGELU_BF16 || EPI == SIG_EPI_BIAS_GELU_BF16) {      // A/B knob: SIG_GEMM_TILE_GELU=128 moves only the GELU epilogues
@@ -989,10 +1007,10 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     bool tall320 = false;
     if (can320 && EPI != SIG_EPI_DGELU_BF16 && EPI != SIG_EPI_DGELUERF_BF16) {
         const int tm160 = (p.M + 159) / 160, t160 = tm160 * (p.N >> 7), t128 = (mp >> 7) * (p.N >> 7);
-        const float c320 = (float)((t320 + 255) / 256) * 81920.f / 0.83f;
-        const float c256 = big ? (float)(((mp >> 8) * (p.N >> 8) + 255) / 256) * 65536.f / 0.83f : 1e30f;
-        const float c160 = tm160 * 160 <= mp ? (float)((t160 + 511) / 512) * 40960.f / 0.68f : 1e30f;
-        const float c128 = (float)((t128 + 511) / 512) * 32768.f / 0.68f;
+        const float c320 = (float)((t320 + cus - 1) / cus) * 81920.f / 0.83f;
+        const float c256 = big ? (float)(((mp >> 8) * (p.N >> 8) + cus - 1) / cus) * 65536.f / 0.83f : 1e30f;
+        const float c160 = tm160 * 160 <= mp ? (float)((t160 + 2 * cus - 1) / (2 * cus)) * 40960.f / 0.68f : 1e30f;
+        const float c128 = (float)((t128 + 2 * cus - 1) / (2 * cus)) * 32768.f / 0.68f;
         // a tie with 256x256 (c_fc: 4 rounds x 1.25 = 5 rounds) goes to the kernel whose epilogue suits the outputs: with the
         // saved derivative as a second output the natural-orientation stores win (144 vs 153 us in the train step), with
         // one output the 256x256 kernel does (128 vs 132 us at inference)
@@ -1013,7 +1031,7 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
         // tiles have in common at the same k -- all column tiles of a row tile on one XCD read the A panel once (band =
         // all columns: FETCH of the qkv dgrad 342 -> 114 MB of A; 70.5 -> 68 us, c_fc dgrad 91 -> 88.5); with several
         // rounds the weight band that stays L2-resident while the rows sweep by matters instead (choose_band)
-        p.band = t320 <= 256 ? (p.N >> 8) : choose_band(p.N >> 8, p.K, 256);
+        p.band = t320 <= cus ? (p.N >> 8) : choose_band(p.N >> 8, p.K, 256);
         hipLaunchKernelGGL((gemm_nt320_kernel<EPI, DT>), dim3(t320), dim3(512), 147456, st, p, mp);
     } else if (big) {
         static bool attr256 = false;
@@ -1036,7 +1054,8 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
         // 160-row tiles when they need fewer rounds of the chip's 512 slots per unit of work (1.25x a 128-row tile) and
         // their last tile stays inside the 128-row padding of the operand buffers
         const int tn128 = p.N >> 7, t128 = (mp >> 7) * tn128, tm160 = (p.M + 159) / 160, t160 = tm160 * tn128;
-        const float c128 = (float)((t128 + 511) / 512), c160 = 1.25f * (float)((t160 + 511) / 512);
+        const int slots = 2 * cus;
+        const float c128 = (float)((t128 + slots - 1) / slots), c160 = 1.25f * (float)((t160 + slots - 1) / slots);
         bool tall = tm160 * 160 <= mp && c160 < c128;
         static int force_bm = -1;
         if (force_bm < 0) { const char* e = getenv("SIG_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
@@ -1677,7 +1696,7 @@ static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {
             attr256 = true;
         }
         const int tiles = (p.I >> 8) * (p.J >> 8);
-        int split = p.split > 0 ? p.split : 256 / tiles;
+        int split = p.split > 0 ? p.split : free_cus() / tiles;      // one block per CU, one round
         if (split < 1) split = 1;
         if (split > ksteps) split = ksteps;
         const int per = sig_ceil_div(ksteps, split);

@@ -39,6 +39,7 @@ int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st);
 int sig_prof_begin_impl(int epi, int N, int K, int max_launches);
 int sig_prof_end_impl(double* total_ms, int* launches, double* flops);
 int sig_tune_gemm_tile_impl(int tile);
+int sig_tune_reserved_cus_impl(int n);
 
 struct SigGemmTN {
     const bf16_t* P;  // [Mr, ldp], columns I

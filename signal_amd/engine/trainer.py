@@ -8,6 +8,8 @@ unscales, skips the update when a gradient overflowed and the scale backs off / 
 anywhere.  bf16 operands need no scaling (scaler is None)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib
@@ -75,6 +77,11 @@ class TrainStep:
             self.scaler = DeviceLossScaler(hip.flat.device)
         self.world = world_size
         self.reducer = None
+        # CUs left to RCCL's channel workgroups while the gradient buckets are all-reduced under the backward pass: the
+        # one-block-per-CU GEMMs are sized in rounds of the free CUs (include/signal_hip.h, sig_tune_reserved_cus)
+        self.reserved_cus = 0
+        if world_size > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
+            self.reserved_cus = int(os.environ.get("SIGNAL_RESERVED_CUS", "16"))
         if world_size > 1:
             fl = hip.flat
             sizes = {n: fl.byname[n].numel() for n in fl.names}
@@ -99,10 +106,16 @@ class TrainStep:
         hip.flat.grad.zero_()
         out = self.model(img, label=target, cam_label=target_cam, view_label=target_view, training=True, sge=self.stage)
         loss = total_loss(self.cfg, out, self.loss_fn, target, target_cam, self.stage)
-        if self.scaler is None:
-            loss.backward()
-        else:
-            loss.backward(gradient=self.scaler.scale_tensor)
+        if self.reserved_cus:
+            _lib.load().sig_tune_reserved_cus(self.reserved_cus)
+        try:
+            if self.scaler is None:
+                loss.backward()
+            else:
+                loss.backward(gradient=self.scaler.scale_tensor)
+        finally:
+            if self.reserved_cus:
+                _lib.load().sig_tune_reserved_cus(0)      # forward and the optimizer have the chip to themselves
         if self.reducer is not None:
             self.reducer.finish()
             if not self.fused:

@@ -58,6 +58,33 @@ def nt_tile(request):
     lib.sig_tune_gemm_tile(prev)
 
 
+def test_gemm_with_reserved_cus(dev):
+    """sig_tune_reserved_cus only changes tile choice / row split (DDP backward leaves CUs to RCCL): same results."""
+    from signal_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    m = 24768
+    a = torch.randn(m, 2304, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(768, 2304, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+    x = torch.randn(m, 768, generator=g).to(torch.bfloat16).to(dev)
+    ap, xp = padded(a, ops), padded(x, ops)
+    outs = []
+    for reserved in (0, 32):
+        prev = lib.sig_tune_reserved_cus(reserved)
+        try:
+            o = torch.zeros(ops.pad_rows(m), 768, device=dev, dtype=torch.bfloat16)
+            ops.gemm_nt(ap, w, m, ops.BF16, o)
+            dw = torch.zeros(2304, 768, device=dev)
+            ops.gemm_tn(ap, xp, dw)
+            outs.append((o.float(), dw))
+        finally:
+            lib.sig_tune_reserved_cus(prev)
+    ref = a.float() @ w.float().t()
+    assert rel_err(outs[0][0][:m], ref) < 3e-3 and rel_err(outs[1][0][:m], ref) < 3e-3
+    assert rel_err(outs[1][1], outs[0][1]) < 1e-5        # another row split: another summation order, same sums
+
+
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
 def test_gemm_nt_epilogues(dev, dt16, nt_tile, m, n, k):
     ops = _ops()
