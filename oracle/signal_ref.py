@@ -360,11 +360,16 @@ def sim_interact(sd: SD, patches: Tensor, cls: Tensor, mask: Tensor, heads: int 
     return z.reshape(B, 3 * d)
 
 
-def sim_forward(sd: SD, cfg: RefConfig, patches: Tensor, cls: Tensor):
-    """Select_Interactive_Module.forward (useA.py:454-476)."""
+def sim_forward(sd: SD, cfg: RefConfig, patches: Tensor, cls: Tensor, force_mask: Optional[Tensor] = None):
+    """Select_Interactive_Module.forward (useA.py:454-476).
+    force_mask (test aid, [3,B,Lp] bool): use this token selection instead of the module's own.  The selection is a
+    discrete top-k on fp32 scores; a device under test whose 16-bit tokens flip a near-tie selects another token, and
+    everything downstream (features, every gradient) is then compared under the device's selection, while the selection
+    itself is compared separately."""
     with torch.no_grad():
         mask, tie_free = sim_select(sd, patches, cls, cfg.topk)
-    return sim_interact(sd, patches, cls, mask, cfg.sim_heads), mask, tie_free
+    used = mask if force_mask is None else force_mask.to(torch.bool)
+    return sim_interact(sd, patches, cls, used, cfg.sim_heads), mask, tie_free
 
 
 # --------------------------------------------------------------------------- #
@@ -528,8 +533,8 @@ def backbone3(sd: SD, cfg: RefConfig, img: Dict[str, Tensor], cam_label: Optiona
     return torch.stack(ps), torch.stack(cs)
 
 
-def signal_forward_train(sd: SD, cfg: RefConfig, img, cam_label) -> SignalOut:
-    """Signal.forward(training=True) (make_model.py:170-255)."""
+def signal_forward_train(sd: SD, cfg: RefConfig, img, cam_label, force_mask: Optional[Tensor] = None) -> SignalOut:
+    """Signal.forward(training=True) (make_model.py:170-255).  force_mask: see sim_forward."""
     out = SignalOut()
     patches, cls = backbone3(sd, cfg, img, cam_label)
     out.patches, out.cls = patches, cls
@@ -541,7 +546,7 @@ def signal_forward_train(sd: SD, cfg: RefConfig, img, cam_label) -> SignalOut:
             sc = bnneck_train(sd, f"bottleneck_{m}", cls[i]) @ sd[f"classifier_{m}.weight"].t()
             out.pairs.append((sc, cls[i]))
     if cfg.use_a:
-        vt, out.mask, out.tie_free = sim_forward(sd, cfg, patches, cls)
+        vt, out.mask, out.tie_free = sim_forward(sd, cfg, patches, cls, force_mask)
         out.pairs.append((bnneck_train(sd, "bottleneck_var", vt) @ sd["classifier_var.weight"].t(), vt))
     if cfg.use_b:
         out.loss_area = gam_loss(sd, patches)
@@ -560,9 +565,9 @@ def signal_forward_infer(sd: SD, cfg: RefConfig, img, cam_label) -> Tensor:
     return torch.cat([ori, vt], dim=-1)
 
 
-def train_loss(sd: SD, cfg: RefConfig, img, target: Tensor, cam_label: Tensor):
-    """Total loss of one iteration (processor.py:173-256). Returns (loss, parts dict, SignalOut)."""
-    out = signal_forward_train(sd, cfg, img, cam_label)
+def train_loss(sd: SD, cfg: RefConfig, img, target: Tensor, cam_label: Tensor, force_mask: Optional[Tensor] = None):
+    """Total loss of one iteration (processor.py:173-256). Returns (loss, parts dict, SignalOut).  force_mask: see sim_forward."""
+    out = signal_forward_train(sd, cfg, img, cam_label, force_mask)
     parts = {}
     loss = 0.0
     for i, (score, feat) in enumerate(out.pairs):

@@ -11,70 +11,51 @@
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward: x f32 [M,D] -> y (bf16 and/or f32), mean/rstd [M]      (clip/model.py:154-160)
 // ------------------------------------------------------------------------------------------------
-#define LN_FWD_RPW 2   // rows per wave: both rows' loads are requested before either is reduced (one row per wave kept
-                       // 3 KB per wave in flight: 4.8 TB/s)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ yb,
                                                             float* __restrict__ yf, float* __restrict__ mean,
                                                             float* __restrict__ rstd, int M, int D, float eps, int dt) {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_FWD_RPW;
-    if (row0 >= M) return;
-    float4 v[LN_FWD_RPW][LN_MAXV];
-    float s[LN_FWD_RPW];
-#pragma unroll
-    for (int r = 0; r < LN_FWD_RPW; ++r) {
-        const int row = row0 + r < M ? row0 + r : M - 1;          // a clamped row is computed again but not stored
-        const float* xr = x + (size_t)row * D;
-        s[r] = 0.f;
-#pragma unroll
-        for (int it = 0; it < LN_MAXV; ++it) {
-            const int c = lane * 4 + it * 256;
-            if (c < D) v[r][it] = *(const float4*)(xr + c);
-        }
-    }
-    float4 g[LN_MAXV], bt[LN_MAXV];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float4 v[LN_MAXV];
+    float s = 0.f;
 #pragma unroll
     for (int it = 0; it < LN_MAXV; ++it) {
         const int c = lane * 4 + it * 256;
-        if (c < D) { g[it] = *(const float4*)(gamma + c); bt[it] = *(const float4*)(beta + c); }
+        if (c < D) {
+            v[it] = *(const float4*)(xr + c);
+            s += v[it].x + v[it].y + v[it].z + v[it].w;
+        }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float a = v[it].x - mu, b = v[it].y - mu, cc = v[it].z - mu, d = v[it].w - mu;
+            q += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
     }
 #pragma unroll
-    for (int r = 0; r < LN_FWD_RPW; ++r) {
-        const int row = row0 + r;
-#pragma unroll
-        for (int it = 0; it < LN_MAXV; ++it) {
-            const int c = lane * 4 + it * 256;
-            if (c < D) s[r] += v[r][it].x + v[r][it].y + v[r][it].z + v[r][it].w;
-        }
-        const float mu = wave_sum(s[r]) / D;
-        float q = 0.f;
-#pragma unroll
-        for (int it = 0; it < LN_MAXV; ++it) {
-            const int c = lane * 4 + it * 256;
-            if (c < D) {
-                const float a = v[r][it].x - mu, b = v[r][it].y - mu, cc = v[r][it].z - mu, d = v[r][it].w - mu;
-                q += a * a + b * b + cc * cc + d * d;
-            }
-        }
-        const float rs = rsqrtf(wave_sum(q) / D + eps);
-        if (row >= M) break;
-        if (lane == 0) {
-            if (mean) mean[row] = mu;
-            if (rstd) rstd[row] = rs;
-        }
-#pragma unroll
-        for (int it = 0; it < LN_MAXV; ++it) {
-            const int c = lane * 4 + it * 256;
-            if (c < D) {
-                float4 o;
-                o.x = (v[r][it].x - mu) * rs * g[it].x + bt[it].x;
-                o.y = (v[r][it].y - mu) * rs * g[it].y + bt[it].y;
-                o.z = (v[r][it].z - mu) * rs * g[it].z + bt[it].z;
-                o.w = (v[r][it].w - mu) * rs * g[it].w + bt[it].w;
-                if (yf) *(float4*)(yf + (size_t)row * D + c) = o;
-                if (yb) *(uint2*)(yb + (size_t)row * D + c) = make_uint2(pack2_16(o.x, o.y, dt), pack2_16(o.z, o.w, dt));
-            }
+    for (int it = 0; it < LN_MAXV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            float4 o;
+            o.x = (v[it].x - mu) * rs * g.x + b.x;
+            o.y = (v[it].y - mu) * rs * g.y + b.y;
+            o.z = (v[it].z - mu) * rs * g.z + b.z;
+            o.w = (v[it].w - mu) * rs * g.w + b.w;
+            if (yf) *(float4*)(yf + (size_t)row * D + c) = o;
+            if (yb) *(uint2*)(yb + (size_t)row * D + c) = make_uint2(pack2_16(o.x, o.y, dt), pack2_16(o.z, o.w, dt));
         }
     }
 }
@@ -84,7 +65,7 @@ int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* be
     SIG_CHECK_DT(dt, "layernorm_fwd");
     SIG_CHECK_ARG(M > 0 && D > 0 && (D & 3) == 0 && D <= 256 * LN_MAXV, "layernorm_fwd: D=%d unsupported (multiple of 4, <= 1024)", D);
     SIG_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(sig_ceil_div(M, 4 * LN_FWD_RPW)), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32,
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(sig_ceil_div(M, 4)), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32,
                        mean, rstd, M, D, eps, dt);
     SIG_CHECK_LAUNCH("layernorm_fwd");
     return 0;

@@ -170,7 +170,13 @@ def test_full_train_step_vs_oracle(dev, golden, tag, dtype):
     for k, v in sdo.items():
         if v.is_floating_point() and "running_" not in k:
             v.requires_grad_(True)
-    oloss, parts, oout = O.train_loss(sdo, ocfg, img, vid, cam)
+    # The SIM selection is a discrete top-k: where the 16-bit tokens flip a near-tie against the fp32 reference (<= 0.5 %
+    # of the tokens, asserted above; the selection kernel itself is pinned on fp32 tokens in test_model_gpu.py), the
+    # oracle differentiates under the DEVICE's selection -- one other token changes every gradient below SIM by more
+    # than the 1e-3 this comparison resolves (measured: worst-parameter cos 0.9997 -> 0.9974 for one flipped token).
+    flipped = int((hip_mask.astype(np.int8) != g["masks"]).sum())
+    force = torch.from_numpy(hip_mask.astype(bool)) if flipped else None
+    oloss, parts, oout = O.train_loss(sdo, ocfg, img, vid, cam, force_mask=force)
     oloss.backward()
     ref_norm = dict(zip([str(k) for k in g["grad_keys"]], g["grad_norms"]))
     bad = []
