@@ -481,14 +481,37 @@ def id_loss(score: Tensor, target: Tensor, eps: float) -> Tensor:
     return (-t * logp).mean(0).sum()
 
 
-def triplet_soft(feat: Tensor, labels: Tensor) -> Tensor:
-    """TripletLoss() soft-margin with batch-hard mining on un-normalised features
-    (triplet_loss.py:16-31,51-104,121-135)."""
+def pairwise_dist(feat: Tensor) -> Tensor:
+    """euclidean_dist (triplet_loss.py:16-31)."""
     sq = (feat * feat).sum(1, keepdim=True)
-    dist = (sq + sq.t() - 2.0 * feat @ feat.t()).clamp(min=1e-12).sqrt()
+    return (sq + sq.t() - 2.0 * feat @ feat.t()).clamp(min=1e-12).sqrt()
+
+
+def batch_hard(dist: Tensor, labels: Tensor):
+    """hard_example_mining (triplet_loss.py:51-104) as index sets plus, per anchor, the RELATIVE gap between the chosen
+    distance and the runner-up: (pidx, nidx, pgap, ngap).  A gap below the accuracy of the features under test marks a
+    near-tie on which a 16-bit device may legitimately mine the other candidate (test aid, see train_loss)."""
     same = labels[:, None] == labels[None, :]
-    d_ap = torch.where(same, dist, torch.full_like(dist, -float("inf"))).max(1).values
-    d_an = torch.where(same, torch.full_like(dist, float("inf")), dist).min(1).values
+    ap = torch.where(same, dist, torch.full_like(dist, -float("inf")))
+    an = torch.where(same, torch.full_like(dist, float("inf")), dist)
+    sp, sn = ap.sort(1, descending=True), an.sort(1)
+    pgap = (sp.values[:, 0] - sp.values[:, 1]) / sp.values[:, 0] if dist.shape[1] > 1 else torch.ones(len(dist))
+    ngap = (sn.values[:, 1] - sn.values[:, 0]) / sn.values[:, 0] if dist.shape[1] > 1 else torch.ones(len(dist))
+    return sp.indices[:, 0], sn.indices[:, 0], pgap, ngap
+
+
+def triplet_soft(feat: Tensor, labels: Tensor, force_mining=None) -> Tensor:
+    """TripletLoss() soft-margin with batch-hard mining on un-normalised features
+    (triplet_loss.py:16-31,51-104,121-135).  force_mining = (pidx, nidx) (test aid): differentiate under these mined
+    indices instead of the function's own arg-max / arg-min."""
+    dist = pairwise_dist(feat)
+    if force_mining is not None:
+        pidx, nidx = (t.to(torch.int64)[:, None] for t in force_mining)
+        d_ap, d_an = dist.gather(1, pidx).squeeze(1), dist.gather(1, nidx).squeeze(1)
+    else:
+        same = labels[:, None] == labels[None, :]
+        d_ap = torch.where(same, dist, torch.full_like(dist, -float("inf"))).max(1).values
+        d_an = torch.where(same, torch.full_like(dist, float("inf")), dist).min(1).values
     return F.softplus(-(d_an - d_ap)).mean()
 
 
@@ -503,10 +526,10 @@ def triplet_margin(feat: Tensor, labels: Tensor, margin: float) -> Tensor:
     return F.relu(d_ap - d_an + margin).mean()
 
 
-def reid_loss(cfg: RefConfig, score: Tensor, feat: Tensor, target: Tensor) -> Tensor:
+def reid_loss(cfg: RefConfig, score: Tensor, feat: Tensor, target: Tensor, force_mining=None) -> Tensor:
     """loss_func of make_loss (make_loss.py:109-150), label-smooth on, soft triplet."""
     return (cfg.id_loss_weight * id_loss(score, target, cfg.label_smooth_eps)
-            + cfg.triplet_loss_weight * triplet_soft(feat, target))
+            + cfg.triplet_loss_weight * triplet_soft(feat, target, force_mining))
 
 
 # --------------------------------------------------------------------------- #
@@ -565,13 +588,18 @@ def signal_forward_infer(sd: SD, cfg: RefConfig, img, cam_label) -> Tensor:
     return torch.cat([ori, vt], dim=-1)
 
 
-def train_loss(sd: SD, cfg: RefConfig, img, target: Tensor, cam_label: Tensor, force_mask: Optional[Tensor] = None):
-    """Total loss of one iteration (processor.py:173-256). Returns (loss, parts dict, SignalOut).  force_mask: see sim_forward."""
+def train_loss(sd: SD, cfg: RefConfig, img, target: Tensor, cam_label: Tensor, force_mask: Optional[Tensor] = None,
+               force_mining=None):
+    """Total loss of one iteration (processor.py:173-256). Returns (loss, parts dict, SignalOut).  force_mask: see sim_forward.
+    force_mining (test aid): per (score, feat) pair either None or the (pidx, nidx) to differentiate under -- the step has two
+    kinds of DISCRETE decisions (SIM top-k, batch-hard mining); a device whose 16-bit features resolve a near-tie the other
+    way has a different but equally valid gradient, so gradients are compared under the device's decisions and the decisions
+    themselves are compared separately, with the size of the tie stated."""
     out = signal_forward_train(sd, cfg, img, cam_label, force_mask)
     parts = {}
     loss = 0.0
     for i, (score, feat) in enumerate(out.pairs):
-        li = reid_loss(cfg, score, feat, target)
+        li = reid_loss(cfg, score, feat, target, None if force_mining is None else force_mining[i])
         parts[f"reid{i}"] = li.detach()
         loss = loss + li
     if out.loss_area is not None:

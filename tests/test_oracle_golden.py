@@ -118,6 +118,19 @@ def test_g6_reid(golden):
     close(trl, g["tri_loss"], rtol=1e-5)
     close(score.grad[:2], g["dscore_rows"], rtol=1e-4, atol=1e-8)
     close(feat.grad.norm(dim=1), g["dfeat_norm"], rtol=1e-4)
+    # the forced-mining test aid: the function's own indices reproduce it bit for bit, other indices change it
+    pi, ni, pgap, ngap = O.batch_hard(O.pairwise_dist(feat.detach()), target)
+    f2 = feat.detach().clone().requires_grad_(True)
+    t2 = O.triplet_soft(f2, target, force_mining=(pi, ni))
+    t2.backward()
+    assert t2.item() == trl.item() and (pgap > 0).all() and (ngap > 0).all()
+    f3 = feat.detach().clone().requires_grad_(True)
+    O.triplet_soft(f3, target).backward()
+    assert torch.equal(f2.grad, f3.grad)
+    ni2 = ni.clone()
+    ni2[0] = (ni[0] + 1) % 4 + (8 if target[0] == target[3] else 0)     # another negative of anchor 0 (ids come in blocks of 4)
+    assert target[ni2[0]] != target[0]
+    assert O.triplet_soft(feat.detach(), target, force_mining=(pi, ni2)).item() != trl.item()
 
 
 @pytest.mark.parametrize("tag", ["rgbnt201", "rgbnt100"])

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import signal_ref as O
-from tests.test_model_gpu import build, make_cfg, rel_err
+from tests.test_model_gpu import FEAT_TOL, build, make_cfg, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -138,9 +138,8 @@ def test_sim_backward_vs_oracle(dev, dtype):
 @pytest.mark.parametrize("tag", ["rgbnt201", "rgbnt100"])
 def test_full_train_step_vs_oracle(dev, golden, tag, dtype):
     """Loss terms and every parameter gradient of one training iteration at real size (B=8: 2 ids x 4), both operand types.
-    fp16 (the north_star bar): loss terms <= 1e-3 of the reference fixture, every parameter's gradient cos >= 0.999.
-    Measured (tools/dtype_probe.py): fp16 losses 1-4e-5, whole-gradient cos 0.999999, worst parameter 0.99982;
-    bf16 losses 2e-4, whole-gradient cos 0.99995, worst parameter 0.9973 ... 0.99967 depending on 1-ulp rounding choices."""
+    fp16 (the north_star bar): loss terms <= 1e-3 of the reference fixture, every parameter's gradient cos >= 0.9999;
+    bf16: losses <= 2e-3, every parameter >= 0.9995 (measured 0.99985 = the operand-rounding floor)."""
     from signal_amd.layers.make_loss import make_loss, total_loss
     g = golden(f"g7_step_{tag}")
     ocfg = O.rgbnt201_config(num_instance=4) if tag == "rgbnt201" else O.rgbnt100_config(num_instance=4)
@@ -166,44 +165,81 @@ def test_full_train_step_vs_oracle(dev, golden, tag, dtype):
     agree = (hip_mask.astype(np.int8) == g["masks"]).mean()
     assert agree > 0.995, agree
     # ---- gradients against the reference's per-parameter norms and the oracle's full gradients ----
-    sdo = {k: v.clone() for k, v in sd.items()}
-    for k, v in sdo.items():
-        if v.is_floating_point() and "running_" not in k:
-            v.requires_grad_(True)
-    # The SIM selection is a discrete top-k: where the 16-bit tokens flip a near-tie against the fp32 reference (<= 0.5 %
-    # of the tokens, asserted above; the selection kernel itself is pinned on fp32 tokens in test_model_gpu.py), the
-    # oracle differentiates under the DEVICE's selection -- one other token changes every gradient below SIM by more
-    # than the 1e-3 this comparison resolves (measured: worst-parameter cos 0.9997 -> 0.9974 for one flipped token).
+    # The step has two kinds of DISCRETE decisions: the SIM top-k selection and the batch-hard triplet mining.  Where the
+    # device's 16-bit features resolve a near-tie the other way, its gradient is a different, equally valid one: conv1 and
+    # the attention weights drop to cos 0.997 with +1 % norm for ONE flipped hard negative (fixture gaps: 1.4e-4 / 2.8e-4
+    # relative, below the 3.7e-3 bf16 feature error; tests/probes/grad_probe_gpu.py, round-2's unexplained 0.9974), and the
+    # SIM cross-attention weights to 0.9995 for five flipped tokens.  So: (1) the decisions are compared on their own --
+    # every deviation must be a near-tie in the fp32 oracle, and their number is bounded; (2) the gradients are compared
+    # TIGHTLY under the device's decisions; (3) and loosely against the oracle's own decisions.
+    def grads_of_oracle(force_mask, force_mining):
+        sdo = {k: v.clone() for k, v in sd.items()}
+        for k, v in sdo.items():
+            if v.is_floating_point() and "running_" not in k:
+                v.requires_grad_(True)
+        oloss, parts, oout = O.train_loss(sdo, ocfg, img, vid, cam, force_mask=force_mask, force_mining=force_mining)
+        oloss.backward()
+        return sdo, oout
+
     flipped = int((hip_mask.astype(np.int8) != g["masks"]).sum())
-    force = torch.from_numpy(hip_mask.astype(bool)) if flipped else None
-    oloss, parts, oout = O.train_loss(sdo, ocfg, img, vid, cam, force_mask=force)
-    oloss.backward()
+    npairs = (len(out) - 3) // 2
+    dev_mining = []
+    for i in range(npairs):
+        pi, ni, _, _ = O.batch_hard(O.pairwise_dist(out[2 + 2 * i].detach().float().cpu()), vid)
+        dev_mining.append((pi, ni))
+    sdo, oout = grads_of_oracle(torch.from_numpy(hip_mask.astype(bool)) if flipped else None, dev_mining)
+    tie = 2 * FEAT_TOL[dtype]                       # a relative distance gap the 16-bit features cannot resolve
+    mining_flips = 0
+    for i, (_, feat) in enumerate(oout.pairs):
+        pi, ni, pgap, ngap = O.batch_hard(O.pairwise_dist(feat.detach()), vid)
+        for mine, own, gap in ((dev_mining[i][0], pi, pgap), (dev_mining[i][1], ni, ngap)):
+            diff = (mine != own).nonzero().flatten().tolist()
+            mining_flips += len(diff)
+            assert all(float(gap[a_]) < tie for a_ in diff), (i, diff, gap)     # only genuine near-ties may be mined differently
+    assert mining_flips <= 2, mining_flips
+    print(f"[train step {tag} {dtype}] SIM tokens flipped {flipped} of {hip_mask.size}, batch-hard choices flipped {mining_flips}")
     ref_norm = dict(zip([str(k) for k in g["grad_keys"]], g["grad_norms"]))
-    bad = []
     named = dict(model.named_parameters())
     # the fixture harness left the BNNeck biases trainable; the reference freezes them (make_model.py:78,88,...)
     frozen = {k for k in ref_norm if k.startswith("bottleneck") and k.endswith(".bias")}
     assert all(not named[k].requires_grad for k in frozen)
     assert {k for k, p in named.items() if p.grad is not None} == set(ref_norm) - frozen, "same set of parameters must receive gradients"
-    # per parameter: fp16 0.999 (the north_star bar; measured worst 0.99982).  bf16: the attention-branch weights of the
-    # lowest blocks sit at 0.9997 with one rounding of the LayerNorm outputs and at 0.9973 with another that differs by one
-    # 16-bit ulp on a few elements (both within 1 ulp of exact; tools/ln_probe.py) -- their gradients are small sums of large
-    # per-token terms, so 2^-9 operand noise shows -- hence 0.995 per parameter there and the tight bound on the WHOLE gradient.
-    pc = 0.999 if dtype == "fp16" else 0.995
-    all_h, all_o = [], []
-    for k, rn in ref_norm.items():
-        if k in frozen:
-            continue
-        gh, go = named[k].grad / scale, sdo[k].grad
-        all_h.append(gh.detach().float().cpu().reshape(-1)); all_o.append(go.detach().float().reshape(-1))
-        if rn < 1e-5:       # exactly-zero gradients in exact arithmetic (bias in front of a BatchNorm)
-            continue
-        c, ratio = cos(gh, go), float(gh.norm()) / rn
-        if c < pc or abs(ratio - 1) > (2e-2 if dtype == "fp16" else 5e-2):
-            bad.append((k, round(c, 5), round(ratio, 4)))
-    assert not bad, bad
-    whole = cos(torch.cat(all_h), torch.cat(all_o))
-    assert whole > (0.99999 if dtype == "fp16" else 0.9995), whole      # measured 0.999999 / 0.99995
+
+    def compare(sdo, pc, pw, check_norm):
+        bad, all_h, all_o, worst = [], [], [], 1.0
+        for k, rn in ref_norm.items():
+            if k in frozen:
+                continue
+            gh, go = named[k].grad / scale, sdo[k].grad
+            all_h.append(gh.detach().float().cpu().reshape(-1)); all_o.append(go.detach().float().reshape(-1))
+            if rn < 1e-5:       # exactly-zero gradients in exact arithmetic (bias in front of a BatchNorm)
+                continue
+            c, ratio = cos(gh, go), float(gh.norm()) / float(go.norm())
+            worst = min(worst, c)
+            # (a scalar's "norm" is the value itself: GAM's temperature gradient is a cancelling sum over the B x B volumes,
+            #  3.4 % off on bf16 features that are 3.8e-3 off; pinned at 1e-3 on exact features by the G4 fixture test)
+            ntol = (5e-3 if dtype == "fp16" else 2e-2) * (3 if go.numel() == 1 else 1)
+            if c < pc or (check_norm and abs(ratio - 1) > ntol):
+                bad.append((k, round(c, 5), round(ratio, 4)))
+        assert not bad, bad
+        whole = cos(torch.cat(all_h), torch.cat(all_o))
+        assert whole > pw, whole
+        return worst, whole
+
+    # (2) under the device's decisions.  Measured (shipped library): fp16 every parameter 1.00000, bf16 >= 0.99985 -- what the
+    # CPU emulation of the 16-bit rounding points predicts (tests/probes/bf16_emulation.py: 0.99986), uniform over the blocks.
+    worst, whole = compare(sdo, 0.9999 if dtype == "fp16" else 0.9995, 0.99999 if dtype == "fp16" else 0.9998, True)
+    print(f"[train step {tag} {dtype}] under the device's decisions: worst parameter cos {worst:.6f}, whole gradient {whole:.7f}")
+    if not flipped and not mining_flips:
+        # the reference's per-parameter gradient norms (fixture G7) apply when no decision differs
+        for k, rn in ref_norm.items():
+            if k not in frozen and rn >= 1e-5:
+                assert abs(float(named[k].grad.norm()) / scale / rn - 1) < (5e-3 if dtype == "fp16" else 2e-2) * (3 if named[k].numel() == 1 else 1), k
+    else:
+        # (3) against the oracle's OWN decisions: bounded by what flipped decisions cost (one hard negative: 0.997)
+        sdo2, _ = grads_of_oracle(None, None)
+        worst, whole = compare(sdo2, 0.995, 0.995, False)
+        print(f"[train step {tag} {dtype}] against the oracle's own decisions: worst parameter cos {worst:.6f}, whole gradient {whole:.7f}")
 
 
 def test_fused_adam_matches_torch(dev):
