@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SIG_ABI_VERSION 2
+#define SIG_ABI_VERSION 3
 
 enum { SIG_DT_BF16 = 0, SIG_DT_F16 = 1 };
 
@@ -75,6 +75,20 @@ int sig_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, 
  * library choose the number of row chunks. */
 int sig_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, int Mr, int I, int J, float* out,
                 int ldo, int split, int dtype, void* stream);
+
+/* n (1..4) weight gradients that share the row count Mr, out_k[I_k,J_k] += P_k[Mr,I_k]^T * Q_k[Mr,J_k], as ONE
+ * launch: the four nn.Linear weights of a ResidualAttentionBlock (modeling/clip/model.py:172-178: attn.in_proj,
+ * attn.out_proj, mlp.c_fc, mlp.c_proj) in one pass over the chip, every CU doing the same number of K-steps
+ * (stream-K over the token rows) and a fixed-order reduce (deterministic; no atomics).  Same operand contract as
+ * sig_gemm_tn; shapes the grouped kernel does not take (I or J not a multiple of 256, short Mr) fall back to
+ * n calls of sig_gemm_tn. */
+typedef struct SigTnJobDesc {
+    const uint16_t* P;   /* dY [Mr, ldp] */
+    const uint16_t* Q;   /* X  [Mr, ldq] */
+    float* out;          /* dW [I, ldo] */
+    int ldp, ldq, ldo, I, J;
+} SigTnJobDesc;
+int sig_gemm_tn_grouped(const SigTnJobDesc* jobs, int n, int Mr, int dtype, void* stream);
 
 /* LayerNorm (fp32 statistics, eps as given): modeling/clip/model.py:154-160, AddModule/useA.py:414-423.
  * y_bf16 / y_f32 / mean / rstd may be NULL when not wanted. */
@@ -218,6 +232,8 @@ typedef struct SigSimParams {
     const float *b_q, *b_kv, *b_o, *b_f1, *b_f2, *n1_w, *n1_b, *n2_w, *n2_b;
     int topk;                                                /* MODEL.TOPK: k1 = topk, k2 = 2*topk */
     int dtype;                                               /* SIG_DT_BF16 / SIG_DT_F16 (selection itself is f32) */
+    int max_keep;                                            /* 0, or int(Lp * MODEL.KEEP_RATIO) when MODEL.FIXED_KEEP_RATIO:
+                                                              * exactly that many tokens per modality (useA.py:253-316) */
 } SigSimParams;
 typedef struct SigSimActs {
     float *qprime, *cconst, *intra, *inter;  /* [B,3,512] [B,3] [B,3,Lp] [B,3,3Lp] : selection scores (raw, pre-softmax) */

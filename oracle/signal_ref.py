@@ -50,6 +50,7 @@ class RefConfig:
     use_a: bool = True                            # MODEL.USE_A  (SIM)
     use_b: bool = True                            # MODEL.USE_B  (GAM+LAM)
     topk: int = 80                                # MODEL.TOPK
+    keep_ratio: Optional[float] = None            # MODEL.KEEP_RATIO when MODEL.FIXED_KEEP_RATIO (make_model.py:107), else None
     stage: str = "together_CLS_Patch"             # MODEL.stageName
     id_loss_weight: float = 0.25
     triplet_loss_weight: float = 1.0
@@ -313,8 +314,36 @@ def _topk_set(scores: Tensor, k: int) -> Tuple[Tensor, Tensor]:
     return mask, tie_free
 
 
-def sim_select(sd: SD, patches: Tensor, cls: Tensor, topk: int):
-    """TokenSelection.forward without the keep-ratio branch (useA.py:223-251).
+def keep_ratio_trim(mask: Tensor, patches: Tensor, cls: Tensor, keep_ratio: float):
+    """The exact keep-ratio branch of TokenSelection.forward (useA.py:253-316): every (sample, modality) keeps exactly
+    max_keep = int(Lp * keep_ratio) tokens.  More selected than that: the max_keep of the SELECTED tokens with the largest
+    RAW intra-modal dot product cls . patch (un-scaled, no softmax, :259-261) stay; fewer: the best un-selected ones are added.
+    Returns (mask, tie_free [B])."""
+    M, B, Lp, _ = patches.shape
+    max_keep = int(Lp * keep_ratio)
+    raw = torch.einsum("mbd,mbld->mbl", cls, patches)
+    out = mask.clone()
+    tie_free = torch.ones(B, dtype=torch.bool)
+    for m in range(M):
+        for b in range(B):
+            cur = mask[m, b]
+            cnt = int(cur.sum())
+            if cnt > max_keep:
+                idx = cur.nonzero().flatten()
+                keep, tf = _topk_set(raw[m, b, idx], max_keep)
+                out[m, b] = False
+                out[m, b, idx[keep]] = True
+                tie_free[b] &= tf
+            elif cnt < max_keep:
+                idx = (~cur).nonzero().flatten()
+                add, tf = _topk_set(raw[m, b, idx], min(max_keep - cnt, len(idx)))
+                out[m, b, idx[add]] = True
+                tie_free[b] &= tf
+    return out, tie_free
+
+
+def sim_select(sd: SD, patches: Tensor, cls: Tensor, topk: int, keep_ratio: Optional[float] = None):
+    """TokenSelection.forward (useA.py:223-316; keep_ratio = the optional exact-count branch :253-316).
     patches [3,B,Lp,d], cls [3,B,d]. Returns (mask [3,B,Lp] bool, tie_free [B] bool)."""
     M, B, Lp, _ = patches.shape
     k1, k2 = topk, 2 * topk
@@ -330,7 +359,11 @@ def sim_select(sd: SD, patches: Tensor, cls: Tensor, topk: int):
         m_inter[a] |= sel[:, :Lp]
         m_inter[b] |= sel[:, Lp:]
         tie_free &= tf
-    return m_intra | m_inter, tie_free
+    mask = m_intra | m_inter
+    if keep_ratio is not None:
+        mask, tf = keep_ratio_trim(mask, patches, cls, keep_ratio)
+        tie_free &= tf
+    return mask, tie_free
 
 
 def gelu_erf(x: Tensor) -> Tensor:
@@ -367,7 +400,7 @@ def sim_forward(sd: SD, cfg: RefConfig, patches: Tensor, cls: Tensor, force_mask
     everything downstream (features, every gradient) is then compared under the device's selection, while the selection
     itself is compared separately."""
     with torch.no_grad():
-        mask, tie_free = sim_select(sd, patches, cls, cfg.topk)
+        mask, tie_free = sim_select(sd, patches, cls, cfg.topk, cfg.keep_ratio)
     used = mask if force_mask is None else force_mask.to(torch.bool)
     return sim_interact(sd, patches, cls, used, cfg.sim_heads), mask, tie_free
 

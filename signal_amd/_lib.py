@@ -21,6 +21,7 @@ SIGNATURES = {
     "sig_tune_reserved_cus": [_i],
     "sig_gemm_nt": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "sig_gemm_tn": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "sig_gemm_tn_grouped": [_vp, _i, _i, _i, _vp],
     "sig_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
     "sig_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sig_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -47,6 +48,10 @@ class SigVitDims(C.Structure):
     _fields_ = [(n, _i) for n in ("S", "B", "L", "D", "H", "F", "out_dim", "dtype")]
 
 
+class SigTnJobDesc(C.Structure):
+    _fields_ = [("P", _vp), ("Q", _vp), ("out", _vp)] + [(n, _i) for n in ("ldp", "ldq", "ldo", "I", "J")]
+
+
 SigEmbedParams = _struct("SigEmbedParams", ["w_conv", "class_embedding", "positional_embedding", "cv_embed", "ln_w", "ln_b"],
                          [("sie_coe", _f)])
 SigEmbedActs = _struct("SigEmbedActs", ["patches", "tok", "pre_ln", "mean", "rstd", "x0"])
@@ -63,7 +68,7 @@ SigHeadActs = _struct("SigHeadActs", ["x", "hp", "mean", "rstd", "tokens"])
 SigHeadGrads = _struct("SigHeadGrads", ["proj", "ln_w", "ln_b"])
 SigSimParams = _struct("SigSimParams", ["sel_wq", "sel_bq", "sel_wk", "sel_bk", "w_q", "w_kv", "w_o", "w_f1", "w_f2",
                                          "wt_q", "wt_kv", "wt_o", "wt_f1", "wt_f2", "b_q", "b_kv", "b_o", "b_f1", "b_f2",
-                                         "n1_w", "n1_b", "n2_w", "n2_b"], [("topk", _i), ("dtype", _i)])
+                                         "n1_w", "n1_b", "n2_w", "n2_b"], [("topk", _i), ("dtype", _i), ("max_keep", _i)])
 SigSimActs = _struct("SigSimActs", ["qprime", "cconst", "intra", "inter", "mask_f", "mask_u8", "sel", "cls_b", "cls_f", "qh",
                                      "kv", "probs", "ao", "y", "z1", "z1_b", "mean1", "rstd1", "f1_pre", "f1", "y2", "mean2",
                                      "rstd2", "out"])

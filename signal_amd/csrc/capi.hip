@@ -46,6 +46,16 @@ int sig_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, int Mr, 
     return sig_launch_gemm_tn(p, (hipStream_t)stream);
 }
 
+int sig_gemm_tn_grouped(const SigTnJobDesc* jobs, int n, int Mr, int dtype, void* stream) {
+    SIG_CHECK_ARG(jobs && n >= 1 && n <= SIG_TN_MAX_JOBS, "gemm_tn_grouped: 1..%d jobs", SIG_TN_MAX_JOBS);
+    SigTnJob j[SIG_TN_MAX_JOBS];
+    for (int k = 0; k < n; ++k) {
+        j[k].P = jobs[k].P; j[k].Q = jobs[k].Q; j[k].out = jobs[k].out;
+        j[k].ldp = jobs[k].ldp; j[k].ldq = jobs[k].ldq; j[k].ldo = jobs[k].ldo; j[k].I = jobs[k].I; j[k].J = jobs[k].J;
+    }
+    return sig_launch_gemm_tn_grouped(j, n, Mr, dtype, (hipStream_t)stream);
+}
+
 int sig_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y_bf16, float* y_f32, float* mean,
                       float* rstd, int M, int D, float eps, int dtype, void* stream) {
     return sig_launch_layernorm_fwd(x, gamma, beta, y_bf16, y_f32, mean, rstd, M, D, eps, dtype, (hipStream_t)stream);

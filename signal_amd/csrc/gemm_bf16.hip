@@ -942,6 +942,18 @@ int sig_prof_end_impl(double* total_ms, int* launches, double* flops) {
 }
 
 
+bool sig_prof_tn_start(hipStream_t st, int I, int J) {
+    const bool timed = g_prof.on && g_prof.epi == SIG_PROF_TN256 && (g_prof.N == 0 || (g_prof.N == I && g_prof.K == J)) &&
+                       g_prof.used + 2 <= g_prof.ev.size();
+    if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+    return timed;
+}
+void sig_prof_tn_stop(hipStream_t st, double flops) {
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    g_prof.used += 2;
+    g_prof.flops += flops;
+}
+
 static int choose_band(int tn, int K, int BN) {
     static int force = -1;       // SIG_GEMM_BAND=<column tiles per band> (A/B knob; must divide the tile count)
     if (force < 0) { const char* e = getenv("SIG_GEMM_BAND"); force = e ? atoi(e) : 0; }
@@ -964,6 +976,7 @@ static int free_cus() {
     const int f = 256 - g_reserved_cus;
     return f < 64 ? 64 : f;
 }
+int sig_free_cus() { return free_cus(); }
 int sig_tune_reserved_cus_impl(int n) {
     const int prev = g_reserved_cus < 0 ? 0 : g_reserved_cus;
     g_reserved_cus = n < 0 ? 0 : (n > 192 ? 192 : n);

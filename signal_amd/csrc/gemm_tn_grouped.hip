@@ -1,0 +1,344 @@
+// Weight gradients of one transformer block as ONE launch: dW_k = dY_k^T X_k for up to 4 (dY, X) pairs that share the row
+// count (the token rows M).  Reference: the four nn.Linear of a ResidualAttentionBlock, modeling/clip/model.py:172-178
+// (attn.in_proj, attn.out_proj, mlp.c_fc, mlp.c_proj); their weight gradients are what autograd's mm backward computes.
+//
+// Work decomposition ("stream-K" over the contraction): the 256x256 output tiles of all jobs are numbered consecutively
+// (a block of the ViT: 27 + 9 + 36 + 36 = 108 tiles), every tile is `ks` K-steps of 64 token rows long, and the
+// tiles * ks K-steps are cut into `grid` equal contiguous ranges, one per workgroup = one per CU.  A range is shorter than a
+// tile (asserted by the launcher), so a workgroup runs at most two segments (the tail of one tile, the head of the next);
+// each segment's 256x256 partial goes to its own workspace slot in MFMA-fragment order, and tn_group_reduce_kernel adds the
+// 2-4 partials of every tile in a fixed order into dW (deterministic, no atomics).
+// Against one launch per weight with a uniform row split (the round-2 form): the K-loops are 164 K-steps instead of 14-56
+// (prologue, first-stage HBM latency and the 256-KB store tail amortised 3-10x better), every CU gets the same amount of work
+// whatever the tile counts are, partial-tile traffic is 2.4x the size of dW instead of 7-28x, and 4 + 4 launches become 1 + 1.
+//
+// The main loop is gemm_tn256x16_kernel's (gemm_bf16.hip): 8 waves x (128 x 64) as 8 x 4 mfma_f32_16x16x32, operands
+// row-major over M staged by LDS-DMA (2 x 64 KB stages), read with pairs of ds_read_b64_tr_b16, 4 phases per K-step with
+// counted lgkmcnt waits, one barrier per K-step.
+#include <type_traits>
+
+#include "sig_kernels.h"
+
+#define TNG_MIN 8   // a segment shorter than this many K-steps is given to the neighbouring workgroup (range ends snap to tile edges)
+
+struct SigTnGroup {
+    SigTnJob job[SIG_TN_MAX_JOBS];
+    int tile0[SIG_TN_MAX_JOBS + 1];   // first tile of each job; tile0[njobs] = tiles
+    int njobs, tiles, ks, grid;
+    float* ws;                        // [2 * grid] slots of 65536 floats
+};
+
+// first K-step (in tile-major numbering) of workgroup c; c = grid gives the total
+__host__ __device__ static inline int tng_start(int c, int total, int grid, int ks) {
+    long long s = (long long)c * total / grid;
+    const int r = (int)(s % ks);
+    if (r && r < TNG_MIN) s -= r;
+    else if (r > ks - TNG_MIN) s += ks - r;
+    return (int)s;
+}
+
+#define TNG_RDTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define TNG_WAITF4(n, f)                                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                                \
+                 : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]), "+v"(f.lo[3]), "+v"(f.hi[3]))
+#define TNG_WAITF8(n, f, g)                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                                \
+                 : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]), "+v"(f.lo[3]), "+v"(f.hi[3]), \
+                   "+v"(g.lo[0]), "+v"(g.hi[0]), "+v"(g.lo[1]), "+v"(g.hi[1]), "+v"(g.lo[2]), "+v"(g.hi[2]), "+v"(g.lo[3]), "+v"(g.hi[3]))
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
+    constexpr int ROWB = 512, OPB = 64 * ROWB, STAGE = 2 * OPB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int total = p.tiles * p.ks;
+    const int u_beg = tng_start(id, total, p.grid, p.ks), u_end = tng_start(id + 1, total, p.grid, p.ks);
+
+    // transposed-read addressing: lane = 16*G + 4*tq + pp addresses row (8G + tq), columns 4pp.. of a 16-column tile and
+    // receives column (4tq + pp) = lane & 15, rows 8G .. 8G+3 (+4 for the second read)
+    const int G = lane >> 4, tq = (lane >> 2) & 3, pp = lane & 3;
+    const int wi = (wave >> 2) * 128, wj = (wave & 3) * 64;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int swz = (tq << 2) | ((G & 1) << 1);
+    unsigned fp[8], fq[4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        fp[a] = lds0 + (8 * G + tq) * ROWB + (((((wi >> 3) + 2 * a + (pp >> 1)) ^ swz)) << 4) + ((pp & 1) << 3);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        fq[b] = lds0 + OPB + (8 * G + tq) * ROWB + (((((wj >> 3) + 2 * b + (pp >> 1)) ^ swz)) << 4) + ((pp & 1) << 3);
+    struct Frag4 { bf16x4_t lo[4], hi[4]; };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using C4 = std::integral_constant<int, 4>;
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+
+    int u = u_beg;
+#pragma unroll 1
+    for (int seg = 0; seg < 2 && u < u_end; ++seg) {
+        const int t = u / p.ks, k0 = u - t * p.ks;
+        const int tile_end = (t + 1) * p.ks;
+        const int nk = (u_end < tile_end ? u_end : tile_end) - u;
+        int jb = 0;
+#pragma unroll
+        for (int q = 1; q < SIG_TN_MAX_JOBS; ++q)
+            if (q < p.njobs && t >= p.tile0[q]) jb = q;
+        const SigTnJob& job = p.job[jb];
+        const int tl = t - p.tile0[jb], tj = job.J >> 8;
+        const int tile_i = tl / tj, tile_j = tl - tile_i * tj;
+        const int ldp = job.ldp, ldq = job.ldq;
+
+        // DMA: a 1-KB piece = 2 rows x 512 B; 32 pieces per operand and stage, 4 + 4 per wave
+        unsigned po[4], qo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (wave * 4 + j) * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ (((r & 3) << 2) | (((r >> 3) & 1) << 1));
+            po[j] = (unsigned)(r * ldp + c * 8) * 2u;
+            qo[j] = (unsigned)(r * ldq + c * 8) * 2u;
+        }
+        const bf16_t* pbase = job.P + (size_t)k0 * 64 * ldp + (tile_i << 8);
+        const bf16_t* qbase = job.Q + (size_t)k0 * 64 * ldq + (tile_j << 8);
+        const size_t pstep = (size_t)64 * ldp, qstep = (size_t)64 * ldq;
+        auto dma_p = [&](int j, int kt, int stage) { glds16_untracked_s(pbase + kt * pstep, po[j], smem + stage * STAGE + (wave * 4 + j) * 1024); };
+        auto dma_q = [&](int j, int kt, int stage) { glds16_untracked_s(qbase + kt * qstep, qo[j], smem + stage * STAGE + OPB + (wave * 4 + j) * 1024); };
+
+        Frag4 pX, pY, qX, qY;
+        auto rd_p = [&](int stage, auto c_c, auto h_c, Frag4& f) {
+            constexpr int C = decltype(c_c)::value, H = decltype(h_c)::value;
+            const unsigned so = stage * STAGE;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const unsigned ad = fp[H * 4 + a] + so;
+                TNG_RDTR(f.lo[a], ad, C * 32 * ROWB);
+                TNG_RDTR(f.hi[a], ad, C * 32 * ROWB + 4 * ROWB);
+            }
+        };
+        auto rd_q = [&](int stage, auto c_c, Frag4& f) {
+            constexpr int C = decltype(c_c)::value;
+            const unsigned so = stage * STAGE;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned ad = fq[b] + so;
+                TNG_RDTR(f.lo[b], ad, C * 32 * ROWB);
+                TNG_RDTR(f.hi[b], ad, C * 32 * ROWB + 4 * ROWB);
+            }
+        };
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // D[i][j] += sum_m P[m][i] Q[m][j]   (A operand = P fragment, B = Q)
+        auto mma = [&](int half, const Frag4& pf, const Frag4& qf, auto lo_c, auto hi_c) {
+            constexpr int A0 = decltype(lo_c)::value, A1 = decltype(hi_c)::value;
+#pragma unroll
+            for (int a = A0; a < A1; ++a) {
+                const bf16x8_t pa = __builtin_shufflevector(pf.lo[a], pf.hi[a], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const bf16x8_t qb = __builtin_shufflevector(qf.lo[b], qf.hi[b], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[half * 4 + a][b] = mfma16<DT>(pa, qb, acc[half * 4 + a][b]);
+                }
+            }
+        };
+
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dma_p(j, 0, 0); dma_q(j, 0, 0); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        rd_p(0, C0{}, C0{}, pX);
+        rd_q(0, C0{}, qX);
+        if (nk > 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma_p(j, 1, 1);
+        }
+        auto step = [&](int kt, auto more_c, auto more2_c) {
+            constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+            const int st = kt & 1;
+            // P0: pX, qX (16 reads) in flight; pY behind them
+            rd_p(st, C0{}, C1{}, pY);
+            if (MORE) { dma_q(0, kt + 1, st ^ 1); dma_q(1, kt + 1, st ^ 1); dma_q(2, kt + 1, st ^ 1); dma_q(3, kt + 1, st ^ 1); }
+            TNG_WAITF8(8, pX, qX);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, pX, qX, C0{}, C4{});
+            __builtin_amdgcn_sched_barrier(0);
+            // P1: next chunk's P half behind pY, its Q tiles issued half-way through the MFMAs (lgkmcnt is a 4-bit counter:
+            // never more than 16 reads requested at once)
+            rd_p(st, C1{}, C0{}, pX);
+            TNG_WAITF4(8, pY);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, pY, qX, C0{}, C2{});
+            __builtin_amdgcn_sched_barrier(0);
+            rd_q(st, C1{}, qY);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, pY, qX, C2{}, C4{});
+            __builtin_amdgcn_sched_barrier(0);
+            // P2: outstanding pX, qY, then pY
+            rd_p(st, C1{}, C1{}, pY);
+            TNG_WAITF8(8, pX, qY);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, pX, qY, C0{}, C4{});
+            __builtin_amdgcn_sched_barrier(0);
+            // stage boundary: this wave's pieces of the next stage landed, its reads of this stage returned
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                         : "+v"(pY.lo[0]), "+v"(pY.hi[0]), "+v"(pY.lo[1]), "+v"(pY.hi[1]), "+v"(pY.lo[2]), "+v"(pY.hi[2]), "+v"(pY.lo[3]),
+                           "+v"(pY.hi[3])::"memory");
+            __builtin_amdgcn_s_barrier();
+            // P3
+            if (MORE) {
+                rd_p(st ^ 1, C0{}, C0{}, pX);
+                rd_q(st ^ 1, C0{}, qX);
+            }
+            if (MORE2) { dma_p(0, kt + 2, st); dma_p(1, kt + 2, st); dma_p(2, kt + 2, st); dma_p(3, kt + 2, st); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, pY, qY, C0{}, C4{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int kt = 0; kt < nk - 2; ++kt) step(kt, T_{}, T_{});
+        if (nk >= 2) step(nk - 2, T_{}, F_{});
+        step(nk - 1, F_{}, F_{});
+
+        // partial tile in fragment order: float4 (wave, a, b, lane) = rows i = wi + 16a + 4(lane >> 4) .. +3 of column
+        // j = wj + 16b + (lane & 15); one coalesced 1-KB store per MFMA tile and wave
+        f32x4_t* wt = (f32x4_t*)(p.ws + (size_t)(2 * id + seg) * 65536) + (size_t)wave * 32 * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wt[(a * 4 + b) * 64] = acc[a][b];
+        // (after the last stage-boundary barrier no wave reads LDS any more: the next segment's DMA may start at once)
+        u += nk;
+    }
+}
+
+// dW tile t += its partials, in workgroup order.  A block = 16 rows x 64 columns of one tile (the 4 column tiles b of one
+// (wave, a)); float4 index r of a partial tile = ((wave * 8 + a) * 4 + b) * 64 + lane.
+__global__ __launch_bounds__(256) void tn_group_reduce_kernel(SigTnGroup p) {
+    __shared__ float tile[16][68];
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index over all tiles (grid = tiles * 64 exactly)
+    const int t = (int)(q >> 14), r = (int)(q & 16383);
+    const int lane = r & 63, f = r >> 6, wave = f >> 5, a = (f >> 2) & 7, b = f & 3;
+    const int total = p.tiles * p.ks;
+    const int lo = t * p.ks, hi = lo + p.ks;
+    // first workgroup whose range reaches into the tile
+    int c = (int)((long long)lo * p.grid / total);
+    if (c > 0) --c;
+    while (tng_start(c + 1, total, p.grid, p.ks) <= lo) ++c;
+    const f32x4_t* ws4 = (const f32x4_t*)p.ws + r;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    // workgroups c, c+1, ... until one begins at or beyond the tile's end; 4 partials requested before any is added
+    // (fixed order: deterministic).  Workgroup cc's partial of THIS tile is its segment 1 if its range began in the tile before.
+    for (bool more = true; more; c += 4) {
+        f32x4_t v[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = c + k;
+            const int s = cc < p.grid ? tng_start(cc, total, p.grid, p.ks) : hi;
+            const int e = cc < p.grid ? tng_start(cc + 1, total, p.grid, p.ks) : hi;
+            if (s >= hi) more = false;
+            ok[k] = s < hi && e > s;
+            if (ok[k]) v[k] = ws4[(size_t)(2 * cc + (s < lo ? 1 : 0)) * 16384];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ok[k]) acc += v[k];
+    }
+    int jb = 0;
+#pragma unroll
+    for (int k = 1; k < SIG_TN_MAX_JOBS; ++k)
+        if (k < p.njobs && t >= p.tile0[k]) jb = k;
+    const SigTnJob& job = p.job[jb];
+    const int tl = t - p.tile0[jb], tj = job.J >> 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(lane >> 4) * 4 + e][b * 16 + (lane & 15)] = acc[e];
+    __syncthreads();
+    const int row = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+    const int i = (tl / tj) * 256 + (wave >> 2) * 128 + a * 16 + row;
+    const int j = (tl % tj) * 256 + (wave & 3) * 64 + c4;
+    float* o = job.out + (size_t)i * job.ldo + j;
+    const f32x4_t add = *(const f32x4_t*)&tile[row][c4];
+    if ((job.ldo & 3) == 0) {
+        *(f32x4_t*)o = *(const f32x4_t*)o + add;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += add[e];
+    }
+}
+
+// can the grouped kernel take these jobs on `grid` workgroups?  (every output a multiple of 256 x 256, ranges shorter than a tile)
+static bool tng_fits(const SigTnJob* jobs, int njobs, int Mr, int grid, int* tiles_out) {
+    if (njobs < 1 || njobs > SIG_TN_MAX_JOBS || Mr <= 0 || (Mr & 63)) return false;
+    int tiles = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const SigTnJob& j = jobs[k];
+        if (!j.P || !j.Q || !j.out || j.I <= 0 || j.J <= 0 || (j.I & 255) || (j.J & 255)) return false;
+        if ((j.ldp & 7) || (j.ldq & 7) || j.ldp < j.I || j.ldq < j.J || j.ldo < j.J) return false;
+        tiles += (j.I >> 8) * (j.J >> 8);
+    }
+    const int ks = Mr >> 6;
+    *tiles_out = tiles;
+    // a range (+ the snaps at both ends) must stay within one tile length so that a workgroup has at most two segments, and be
+    // long enough that a partial-tile store (256 KB) is amortised: short problems keep the per-weight launches
+    const long long R = (long long)tiles * ks / grid;
+    return R + 1 + 2 * TNG_MIN <= ks && R >= 32;
+}
+
+template <int DT>
+static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int tiles, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)&gemm_tn_group_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_done = true;
+    }
+    SigTnGroup g;
+    memset(&g, 0, sizeof(g));
+    int t0 = 0;
+    double flops = 0;
+    for (int k = 0; k < njobs; ++k) {
+        g.job[k] = jobs[k];
+        g.tile0[k] = t0;
+        t0 += (jobs[k].I >> 8) * (jobs[k].J >> 8);
+        flops += 2.0 * Mr * jobs[k].I * jobs[k].J;
+    }
+    for (int k = njobs; k <= SIG_TN_MAX_JOBS; ++k) g.tile0[k] = t0;
+    g.njobs = njobs; g.tiles = tiles; g.ks = Mr >> 6; g.grid = grid;
+    g.ws = sig_stream_scratch(st, (size_t)2 * grid * 65536 * sizeof(float), 0);
+    SIG_CHECK_ARG(g.ws, "gemm_tn_grouped: no workspace for the partial tiles");
+    const bool timed = sig_prof_tn_start(st, njobs == 1 ? jobs[0].I : 0, njobs == 1 ? jobs[0].J : 0);
+    hipLaunchKernelGGL(gemm_tn_group_kernel<DT>, dim3(grid), dim3(512), 131072, st, g);
+    if (timed) sig_prof_tn_stop(st, flops);
+    SIG_CHECK_LAUNCH("gemm_tn_group");
+    hipLaunchKernelGGL(tn_group_reduce_kernel, dim3(tiles * 64), dim3(256), 0, st, g);
+    SIG_CHECK_LAUNCH("tn_group_reduce");
+    return 0;
+}
+
+int sig_tn_grouped_enabled() {
+    static int on = -1;       // SIG_TN_GROUPED=0: the round-2 form (one launch per weight, uniform row split) for A/B runs
+    if (on < 0) { const char* e = getenv("SIG_TN_GROUPED"); on = e ? atoi(e) : 1; }
+    return on;
+}
+
+int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, hipStream_t st) {
+    SIG_CHECK_DT(dt, "gemm_tn_grouped");
+    SIG_CHECK_ARG(jobs && njobs >= 1 && njobs <= SIG_TN_MAX_JOBS, "gemm_tn_grouped: 1..%d jobs", SIG_TN_MAX_JOBS);
+    const int grid = sig_free_cus();
+    int tiles = 0;
+    if (sig_tn_grouped_enabled() && tng_fits(jobs, njobs, Mr, grid, &tiles))
+        return dt == SIG_DT_F16 ? launch_group<SIG_DT_F16>(jobs, njobs, Mr, grid, tiles, st)
+                                : launch_group<SIG_DT_BF16>(jobs, njobs, Mr, grid, tiles, st);
+    // shapes the grouped kernel does not take (small batches, outputs that are not multiples of 256): one launch per weight
+    for (int k = 0; k < njobs; ++k) {
+        SigGemmTN p{};
+        p.P = jobs[k].P; p.Q = jobs[k].Q; p.ldp = jobs[k].ldp; p.ldq = jobs[k].ldq; p.Mr = Mr; p.I = jobs[k].I; p.J = jobs[k].J;
+        p.out = jobs[k].out; p.ldo = jobs[k].ldo; p.dt = dt;
+        const int rc = sig_launch_gemm_tn(p, st);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -54,6 +54,18 @@ struct SigGemmTN {
     int dt;           // SIG_DT_BF16 / SIG_DT_F16: type of P and Q
 };
 int sig_launch_gemm_tn(const SigGemmTN& p, hipStream_t st);
+// several weight gradients that share the row count, as ONE stream-K launch + one reduce (gemm_tn_grouped.hip)
+#define SIG_TN_MAX_JOBS 4
+struct SigTnJob {
+    const bf16_t* P;  // dY [Mr, ldp], columns I
+    const bf16_t* Q;  // X  [Mr, ldq], columns J
+    float* out;       // dW [I, ldo] f32, +=
+    int ldp, ldq, ldo, I, J;
+};
+int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, hipStream_t st);
+int sig_free_cus();                                            // 256 minus the CUs reserved for RCCL (sig_tune_reserved_cus)
+bool sig_prof_tn_start(hipStream_t st, int I, int J);          // bench.py's roofline leg (class SIG_PROF_TN256)
+void sig_prof_tn_stop(hipStream_t st, double flops);
 // library-owned scratch per (device, stream, slot): nullptr when it cannot be had (callers then fall back to atomics)
 float* sig_stream_scratch(hipStream_t st, size_t bytes, int slot);
 
@@ -80,7 +92,7 @@ int sig_launch_embed_bwd(const float* dx_pre, float* dtok_f32, bf16_t* dtok_bf16
 int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, int dt, hipStream_t st);
 // ---- SIM (sim.hip) ------------------------------------------------------------------------------------
 int sig_launch_sim_select(const float* tokens, int B, int L, const float* Wq, const float* bq, const float* Wk,
-                          const float* bk, int topk, float* qprime, float* cconst, float* intra, float* inter,
+                          const float* bk, int topk, int max_keep, float* qprime, float* cconst, float* intra, float* inter,
                           float* mask_f, unsigned char* mask_u8, hipStream_t st);
 int sig_launch_sim_gather(const float* tokens, const float* mask_f, int B, int L, bf16_t* sel, bf16_t* cls_b, float* cls_f,
                           int dt, hipStream_t st);

@@ -105,7 +105,7 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 }
 
 __global__ __launch_bounds__(256) void sim_select_kernel(const float* __restrict__ intra, const float* __restrict__ inter,
-                                                         int B, int Lp, int k1, int k2, float* __restrict__ mask_f,
+                                                         int B, int Lp, int k1, int k2, int max_keep, float* __restrict__ mask_f,
                                                          unsigned char* __restrict__ mask_u8) {
     __shared__ float pi[3][128], pc[3][384], red[4];
     __shared__ int sel[3][128];
@@ -166,6 +166,33 @@ __global__ __launch_bounds__(256) void sim_select_kernel(const float* __restrict
         }
     }
     __syncthreads();
+    // ---- optional exact keep ratio (useA.py:253-316, MODEL.FIXED_KEEP_RATIO): every modality keeps exactly max_keep tokens,
+    // ranked by the RAW intra-modal dot product (intra[] is that product / sqrt(d): the same order) -- more selected than
+    // max_keep: the best max_keep of the SELECTED stay; fewer: the best un-selected ones are added.  Rank count among the
+    // tokens of the same status, lowest index first on ties. ----
+    if (max_keep > 0) {
+        for (int m = 0; m < 3; ++m) {
+            const int mine = tid < Lp ? sel[m][tid] : 0;
+            const int cnt = (int)(block_sum256((float)mine, red) + 0.5f);
+            if (tid < Lp) pi[m][tid] = intra[((size_t)b * 3 + m) * Lp + tid];      // the softmax rows are no longer needed
+            __syncthreads();
+            int on = mine;
+            if (tid < Lp && cnt != max_keep) {
+                const float v = pi[m][tid];
+                int rank = 0;
+#pragma unroll 16
+                for (int j = 0; j < Lp; ++j) {
+                    const float o = pi[m][j];
+                    rank += (sel[m][j] == mine) && ((o > v) || (o == v && j < tid));
+                }
+                if (cnt > max_keep) on = mine && rank < max_keep;
+                else on = mine || rank < max_keep - cnt;
+            }
+            __syncthreads();
+            if (tid < Lp) sel[m][tid] = on;
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < 3 * Lp; i += 256) {
         const int m = i / Lp, j = i - m * Lp;
         const int on = sel[m][j];
@@ -238,17 +265,18 @@ __global__ __launch_bounds__(256) void sim_gather_bwd_kernel(const bf16_t* __res
 }
 
 int sig_launch_sim_select(const float* tokens, int B, int L, const float* Wq, const float* bq, const float* Wk,
-                          const float* bk, int topk, float* qprime, float* cconst, float* intra, float* inter,
+                          const float* bk, int topk, int max_keep, float* qprime, float* cconst, float* intra, float* inter,
                           float* mask_f, unsigned char* mask_u8, hipStream_t st) {
     SIG_CHECK_ARG(tokens && Wq && bq && Wk && bk && qprime && cconst && intra && inter && (mask_f || mask_u8), "sim_select: null pointer");
     SIG_CHECK_ARG(B > 0 && L > 1 && L - 1 <= 128 && topk > 0, "sim_select: needs 1 <= L-1 <= 128 patches (got %d) and topk > 0", L - 1);
+    SIG_CHECK_ARG(max_keep >= 0 && max_keep <= L - 1, "sim_select: max_keep=%d outside 0..Lp (0 = no exact keep ratio)", max_keep);
     const int Lp = L - 1;
     const int k1 = topk < Lp ? topk : Lp, k2 = 2 * topk < 2 * Lp ? 2 * topk : 2 * Lp;
     hipLaunchKernelGGL(sim_qprime_kernel, dim3(3 * B), dim3(512), 0, st, tokens, L, B, Wq, bq, Wk, bk, qprime, cconst);
     SIG_CHECK_LAUNCH("sim_qprime");
     hipLaunchKernelGGL(sim_scores_kernel, dim3(sig_ceil_div(3 * B * Lp, 4)), dim3(256), 0, st, tokens, L, B, qprime, cconst, intra, inter);
     SIG_CHECK_LAUNCH("sim_scores");
-    hipLaunchKernelGGL(sim_select_kernel, dim3(B), dim3(256), 0, st, intra, inter, B, Lp, k1, k2, mask_f, mask_u8);
+    hipLaunchKernelGGL(sim_select_kernel, dim3(B), dim3(256), 0, st, intra, inter, B, Lp, k1, k2, max_keep, mask_f, mask_u8);
     SIG_CHECK_LAUNCH("sim_select");
     return 0;
 }

@@ -123,22 +123,29 @@ int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
     // ---- MLP ----
     RUN(sig_launch_gemm_nt(with_colsum(nt(dt, dx_out_b, D, p->wt_proj, D, M, F, D, s->du, F, nullptr, nullptr, 0, a->u, F), g->b_fc),
                            SIG_EPI_DGELU_BF16, st));                                              // du = (dx_out W_proj) * QuickGELU'(pre-act), saved by c_fc
-    RUN(sig_launch_gemm_tn(tn(dt, dx_out_b, D, a->g, F, Mp, D, F, g->w_proj, F), st));
     if (!b_proj_done) RUN(sig_launch_colsum_bf16(dx_out_b, D, M, D, g->b_proj, dt, st));
     RUN(sig_launch_gemm_nt(nt(dt, s->du, F, p->wt_fc, F, M, D, F, s->dh, D), SIG_EPI_BF16, st));     // dh2 = du W_fc
-    RUN(sig_launch_gemm_tn(tn(dt, s->du, F, a->h2, D, Mp, F, D, g->w_fc, D), st));
     // dx_mid = dx_out + LN2'(dh2)
     RUN(sig_launch_layernorm_bwd(s->dh, 1, a->x_mid, p->ln2_w, a->mean2, a->rstd2, dx_out, s->dx_mid, s->dx_mid_b, g->ln2_w,
                                  g->ln2_b, M, D, dt, st, g->b_out));
     // ---- attention ----
     RUN(sig_launch_gemm_nt(nt(dt, s->dx_mid_b, D, p->wt_out, D, M, D, D, s->dh, D), SIG_EPI_BF16, st));  // d attn
-    RUN(sig_launch_gemm_tn(tn(dt, s->dx_mid_b, D, a->attn, D, Mp, D, D, g->w_out, D), st));
     // (in_proj bias: every (sequence) workgroup of a head would hit the same 192 addresses -- measured 2x slower with
     //  in-kernel atomics -- so it stays a separate 25 us column-sum pass over dqkv)
     RUN(sig_launch_attn_bwd(a->qkv, a->attn, s->dh, a->lse, s->dqkv, d->S, d->L, d->H, dt, st));
+    // ---- the block's four weight gradients: every (dY, X) pair is still in place here (dx_out_b is overwritten by the last
+    // LayerNorm backward below), so they go as ONE stream-K launch + one reduce (gemm_tn_grouped.hip) ----
+    {
+        const SigTnJob jobs[4] = {
+            {s->dqkv, a->h1, g->w_in, 3 * D, D, D, 3 * D, D},          // attn.in_proj_weight  [3D, D]
+            {s->dx_mid_b, a->attn, g->w_out, D, D, D, D, D},           // attn.out_proj.weight [D, D]
+            {s->du, a->h2, g->w_fc, F, D, D, F, D},                    // mlp.c_fc.weight      [F, D]
+            {dx_out_b, a->g, g->w_proj, D, F, F, D, F},                // mlp.c_proj.weight    [D, F]
+        };
+        RUN(sig_launch_gemm_tn_grouped(jobs, 4, Mp, dt, st));
+    }
     RUN(sig_launch_colsum_bf16(s->dqkv, 3 * D, M, 3 * D, g->b_in, dt, st));
     RUN(sig_launch_gemm_nt(nt(dt, s->dqkv, 3 * D, p->wt_in, 3 * D, M, D, 3 * D, s->dh, D), SIG_EPI_BF16, st));  // dh1
-    RUN(sig_launch_gemm_tn(tn(dt, s->dqkv, 3 * D, a->h1, D, Mp, 3 * D, D, g->w_in, D), st));
     // dx_in = dx_mid + LN1'(dh1)
     RUN(sig_launch_layernorm_bwd(s->dh, 1, a->x_in, p->ln1_w, a->mean1, a->rstd1, s->dx_mid, dx_in, dx_in_b, g->ln1_w, g->ln1_b,
                                  M, D, dt, st, dx_in_colsum));
@@ -180,7 +187,7 @@ int sig_head_bwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs*
 // ------------------------------------------------------------------------------------------------
 int sig_sim_select(const float* tokens, int B, int L, const SigSimParams* p, const SigSimActs* a, void* stream) {
     SIG_CHECK_ARG(tokens && p && a, "sim_select: null argument");
-    return sig_launch_sim_select(tokens, B, L, p->sel_wq, p->sel_bq, p->sel_wk, p->sel_bk, p->topk, a->qprime, a->cconst,
+    return sig_launch_sim_select(tokens, B, L, p->sel_wq, p->sel_bq, p->sel_wk, p->sel_bk, p->topk, p->max_keep, a->qprime, a->cconst,
                                  a->intra, a->inter, a->mask_f, a->mask_u8, (hipStream_t)stream);
 }
 

@@ -268,6 +268,10 @@ class HipPath:
             b_in, gb_in = self._p(inb), self._g(inb)
             self._sim_T = dict(q=torch.zeros(d, d, dtype=self.operand_dtype, device=dev),
                                kv=torch.zeros(d, 2 * d, dtype=self.operand_dtype, device=dev))
+            kr = m.SIM.token_selection.keep_ratio                 # MODEL.KEEP_RATIO when MODEL.FIXED_KEEP_RATIO, else None
+            max_keep = 0 if kr is None else int((self.L - 1) * kr)  # useA.py:255-256
+            if kr is not None and not 1 <= max_keep <= self.L - 1:
+                raise ValueError(f"MODEL.KEEP_RATIO={kr}: int(Lp * ratio) must lie in 1..{self.L - 1}")
             self.sim_p = fill(
                 _lib.SigSimParams, sel_wq=self._p(s + "W_q.weight"), sel_bq=self._p(s + "W_q.bias"),
                 sel_wk=self._p(s + "W_k.weight"), sel_bk=self._p(s + "W_k.bias"),
@@ -279,7 +283,7 @@ class HipPath:
                 b_f1=self._p(mi + "ffn.0.bias"), b_f2=self._p(mi + "ffn.2.bias"),
                 n1_w=self._p(mi + "norm1.weight"), n1_b=self._p(mi + "norm1.bias"),
                 n2_w=self._p(mi + "norm2.weight"), n2_b=self._p(mi + "norm2.bias"), topk=int(m.SIM.token_selection.k1),
-                dtype=self.dt)
+                dtype=self.dt, max_keep=max_keep)
             self.sim_g = fill(
                 _lib.SigSimGrads, w_q=g_in[:d], w_kv=g_in[d:], w_o=self._g(mi + "cross_attn.out_proj.weight"),
                 w_f1=self._g(mi + "ffn.0.weight"), w_f2=self._g(mi + "ffn.2.weight"), b_q=gb_in[:d], b_kv=gb_in[d:],

@@ -59,9 +59,8 @@ class Signal(nn.Module):
                     bn.apply(P.weights_init_kaiming)
                 setattr(self, f"bottleneck_{m}", bn)
         if self.use_A:
-            if cfg.MODEL.FIXED_KEEP_RATIO:
-                raise NotImplementedError("MODEL.FIXED_KEEP_RATIO (off in every shipped config) is not on the HIP path")
-            self.SIM = P.SimParams(self.feat_dim, k=int(cfg.MODEL.TOPK))
+            keep_ratio = cfg.MODEL.KEEP_RATIO if cfg.MODEL.FIXED_KEEP_RATIO else None       # make_model.py:107-108
+            self.SIM = P.SimParams(self.feat_dim, k=int(cfg.MODEL.TOPK), keep_ratio=keep_ratio)
             self.classifier_var = nn.Linear(3 * self.feat_dim, num_classes, bias=False)
             self.classifier_var.apply(P.weights_init_classifier)
             self.bottleneck_var = nn.BatchNorm1d(3 * self.feat_dim)

@@ -107,6 +107,29 @@ def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: torch.Tensor, split: int = 0)
     return out
 
 
+def gemm_tn_grouped(jobs) -> None:
+    """out_k += p_k.T @ q_k for up to 4 (p, q, out) triples with the same row count, as one launch (a transformer block's
+    four weight gradients)."""
+    import ctypes
+    if not 1 <= len(jobs) <= 4:
+        raise ValueError("gemm_tn_grouped: 1..4 jobs")
+    arr = (_lib.SigTnJobDesc * len(jobs))()
+    dt = rows = None
+    for k, (p, q, out) in enumerate(jobs):
+        d = _chk16(p, "gemm_tn_grouped.p")
+        _chk16(q, "gemm_tn_grouped.q", like=p)
+        _chk(out, torch.float32, "gemm_tn_grouped.out")
+        if dt is None:
+            dt, rows = d, p.shape[0]
+        if d != dt or p.shape[0] != rows or q.shape[0] != rows:
+            raise ValueError("gemm_tn_grouped: the jobs must share operand type and row count")
+        if tuple(out.shape) != (p.shape[1], q.shape[1]):
+            raise ValueError(f"gemm_tn_grouped: out {tuple(out.shape)} vs [{p.shape[1]},{q.shape[1]}]")
+        arr[k] = _lib.SigTnJobDesc(p.data_ptr(), q.data_ptr(), out.data_ptr(), p.stride(0), q.stride(0), out.stride(0),
+                                   p.shape[1], q.shape[1])
+    _lib.call("sig_gemm_tn_grouped", ctypes.cast(arr, ctypes.c_void_p), len(jobs), rows, dt, _stream())
+
+
 def layernorm_fwd(x, gamma, beta, m, y_bf16=None, y_f32=None, mean=None, rstd=None, eps=1e-5):
     _chk(x, torch.float32, "layernorm_fwd.x")
     d = x.shape[1]

@@ -168,6 +168,22 @@ def main():
         save(f"g2_sim_{tag}", seed_w=31, seed_x=32, scale=scale, topk=topk, masks=masks,
              tie_free=tie_free.to(torch.int8), interact=out)
 
+    # ---- G2b: the exact keep-ratio branch (useA.py:253-316; MODEL.FIXED_KEEP_RATIO): TOPK 80 leaves more than
+    # int(0.75 * 128) = 96 tokens selected (trim), TOPK 24 fewer (grow) ----
+    for topk, keep, tag in [(80, 0.75, "k80_keep75"), (24, 0.75, "k24_keep75")]:
+        cfg = O.rgbnt201_config(topk=topk, keep_ratio=keep)
+        sd = O.init_state_dict(cfg, seed=31)
+        sim = R.useA.Select_Interactive_Module(cfg.out_dim, k=topk, keep_ratio=keep)
+        _load(sim, {k[len("SIM."):]: v for k, v in sd.items() if k.startswith("SIM.")})
+        patches, cls = head_features(cfg, 8, seed=33)
+        with torch.no_grad():
+            out = sim(patches[0], patches[1], patches[2], cls[0], cls[1], cls[2])
+        masks = torch.stack([sim.token_selection.last_masks[m][..., 0] for m in O.MODALITIES]).to(torch.int8)
+        before, _ = O.sim_select(sd, patches, cls, topk)
+        _, tie_free = O.sim_select(sd, patches, cls, topk, keep)
+        save(f"g2_sim_{tag}", seed_w=31, seed_x=33, scale=1.0, topk=topk, keep_ratio=keep, masks=masks,
+             count_before=before.sum(-1).to(torch.int32), tie_free=tie_free.to(torch.int8), interact=out)
+
     # ---- G4: GAM loss and input gradients (regular + near-degenerate batch) ----
     cfg = O.rgbnt201_config()
     sd = O.init_state_dict(cfg, seed=41)

@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     # the ctypes table binds exactly the header's int-returning functions
     bound = set(_lib.SIGNATURES) | {"sig_last_error", "sig_version"}
     assert bound == set(syms), bound ^ set(syms)
-    assert lib.sig_version() == 2
+    assert lib.sig_version() == 3
 
 
 def test_struct_layouts_match_header():

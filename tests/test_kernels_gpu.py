@@ -82,7 +82,41 @@ def test_gemm_with_reserved_cus(dev):
             lib.sig_tune_reserved_cus(prev)
     ref = a.float() @ w.float().t()
     assert rel_err(outs[0][0][:m], ref) < 3e-3 and rel_err(outs[1][0][:m], ref) < 3e-3
+    dw_ref = a.double().t() @ x.double()                 # the exact product of the 16-bit operands
+    assert rel_err(outs[0][1], dw_ref) < 5e-6 and rel_err(outs[1][1], dw_ref) < 5e-6
     assert rel_err(outs[1][1], outs[0][1]) < 1e-5        # another row split: another summation order, same sums
+
+
+# the four weight gradients of a transformer block at the benched size (B = 64: M = 24 768 token rows padded to 24 832):
+# dW = dY^T X for in_proj, out_proj, c_fc, c_proj -- the shapes the headline's roofline kernel runs
+HEADLINE_TN = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+
+
+@pytest.mark.parametrize("i,j", HEADLINE_TN)
+@pytest.mark.parametrize("reserved", [0, 16])
+def test_gemm_tn_headline_shapes_vs_fp64(dev, dt16, i, j, reserved):
+    """The big-tile weight-gradient path at the shapes bench.py times, default row split and the DDP (reserved CUs) split,
+    against the exact product of the same 16-bit operands (f64 on the device) -- not against itself."""
+    from signal_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    m, mr = 24768, 24832
+    g = torch.Generator(device="cpu").manual_seed(i * 7 + j)
+    p = torch.zeros(mr, i, dtype=dt16, device=dev)
+    q = torch.zeros(mr, j, dtype=dt16, device=dev)
+    # asymmetric, column-dependent operands (a transposed or column-permuted result cannot pass)
+    p[:m] = (torch.randn(m, i, generator=g) * 0.1 + torch.linspace(-0.1, 0.2, i)[None]).to(dt16).to(dev)
+    q[:m] = (torch.randn(m, j, generator=g) + torch.linspace(0.3, -0.2, j)[None]).to(dt16).to(dev)
+    ref = p.double().t() @ q.double()
+    prev = lib.sig_tune_reserved_cus(reserved)
+    try:
+        out = torch.zeros(i, j, device=dev)
+        ops.gemm_tn(p, q, out)
+        assert rel_err(out, ref) < 5e-6, (i, j, reserved)
+        ops.gemm_tn(p, q, out)                           # accumulates into dW
+        assert rel_err(out, 2 * ref) < 5e-6
+    finally:
+        lib.sig_tune_reserved_cus(prev)
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -330,3 +364,57 @@ def test_gemm_error_budget_per_operand_type(dev, n, k):
     assert 1.5e-3 < errs[torch.bfloat16] < 3.5e-3
     assert errs[torch.float16] < 4.5e-4
     assert 6.0 < errs[torch.bfloat16] / errs[torch.float16] < 10.0     # 3 more mantissa bits
+
+
+@pytest.mark.parametrize("reserved", [0, 16])
+@pytest.mark.parametrize("mr", [24832, 24832 - 64 * 5, 12416])
+def test_gemm_tn_grouped_block_shapes_vs_fp64(dev, dt16, mr, reserved):
+    """The four weight gradients of a transformer block in ONE stream-K launch (gemm_tn_grouped.hip), at the benched row
+    count (B = 64: 24 832 padded token rows), a row count that is not a multiple of the range length, and B = 32; against
+    the exact f64 product of the same 16-bit operands; accumulation into dW; default grid and the DDP (reserved CUs) grid."""
+    from signal_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    D, F = 768, 3072
+    g = torch.Generator(device="cpu").manual_seed(mr + reserved)
+
+    def operand(cols, scale, lo, hi):
+        t = torch.zeros(mr, cols, dtype=dt16, device=dev)
+        m = mr - 37                                   # the last rows are zero padding, as in the model
+        t[:m] = (torch.randn(m, cols, generator=g) * scale + torch.linspace(lo, hi, cols)[None]).to(dt16).to(dev)
+        return t
+    dqkv, h1 = operand(3 * D, 0.1, -0.1, 0.2), operand(D, 1.0, 0.3, -0.2)
+    dxm, attn = operand(D, 0.1, 0.05, -0.1), operand(D, 1.0, -0.2, 0.1)
+    du, h2 = operand(F, 0.1, -0.2, 0.1), operand(D, 1.0, 0.1, 0.4)
+    dxo, gact = operand(D, 0.1, 0.1, -0.05), operand(F, 1.0, -0.3, 0.3)
+    pairs = [(dqkv, h1), (dxm, attn), (du, h2), (dxo, gact)]
+    outs = [torch.zeros(p.shape[1], q.shape[1], device=dev) for p, q in pairs]
+    prev = lib.sig_tune_reserved_cus(reserved)
+    try:
+        ops.gemm_tn_grouped([(p, q, o) for (p, q), o in zip(pairs, outs)])
+        for (p, q), o in zip(pairs, outs):
+            assert rel_err(o, p.double().t() @ q.double()) < 5e-6, (tuple(o.shape), mr, reserved)
+        ops.gemm_tn_grouped([(p, q, o) for (p, q), o in zip(pairs, outs)])           # += semantics
+        for (p, q), o in zip(pairs, outs):
+            assert rel_err(o, 2 * (p.double().t() @ q.double())) < 5e-6
+        # a two-job group and determinism (fixed-order reduce): bit-identical repeats
+        a1, a2 = torch.zeros(3 * D, D, device=dev), torch.zeros(F, D, device=dev)
+        b1, b2 = torch.zeros(3 * D, D, device=dev), torch.zeros(F, D, device=dev)
+        ops.gemm_tn_grouped([(dqkv, h1, a1), (du, h2, a2)])
+        ops.gemm_tn_grouped([(dqkv, h1, b1), (du, h2, b2)])
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+        assert rel_err(a2, du.double().t() @ h2.double()) < 5e-6
+    finally:
+        lib.sig_tune_reserved_cus(prev)
+
+
+def test_gemm_tn_grouped_falls_back_on_small_problems(dev):
+    """B = 8 (3 200 rows) and outputs that are not multiples of 256 take the per-weight launches: same results."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mr = 3200
+    p1, q1 = torch.randn(mr, 2304, generator=g).bfloat16().to(dev), torch.randn(mr, 768, generator=g).bfloat16().to(dev)
+    p2, q2 = torch.randn(mr, 384, generator=g).bfloat16().to(dev), torch.randn(mr, 128, generator=g).bfloat16().to(dev)
+    o1, o2 = torch.zeros(2304, 768, device=dev), torch.zeros(384, 128, device=dev)
+    ops.gemm_tn_grouped([(p1, q1, o1), (p2, q2, o2)])
+    assert rel_err(o1, p1.double().t() @ q1.double()) < 5e-6 and rel_err(o2, p2.double().t() @ q2.double()) < 5e-6

@@ -36,6 +36,8 @@ def make_cfg(ocfg: O.RefConfig, dtype="bf16"):
     c.MODEL.SIE_CAMERA = ocfg.sie_camera
     c.MODEL.DIRECT = ocfg.direct
     c.MODEL.USE_A, c.MODEL.USE_B, c.MODEL.TOPK = ocfg.use_a, ocfg.use_b, ocfg.topk
+    if ocfg.keep_ratio is not None:
+        c.MODEL.FIXED_KEEP_RATIO, c.MODEL.KEEP_RATIO = True, ocfg.keep_ratio
     c.MODEL.stageName = ocfg.stage
     c.MODEL.ID_LOSS_WEIGHT, c.MODEL.TRIPLET_LOSS_WEIGHT = ocfg.id_loss_weight, ocfg.triplet_loss_weight
     c.MODEL.Gram_Loss_weight, c.MODEL.PAT_Loss_weight = ocfg.gram_loss_weight, ocfg.pat_loss_weight
@@ -90,7 +92,7 @@ def test_inference_features_vs_oracle(dev, tag, dtype):
         assert rel_err(feat[same][:, 1536:], ref[same][:, 1536:]) < tol
 
 
-def hip_sim_select(dev, sd, patches, cls, topk):
+def hip_sim_select(dev, sd, patches, cls, topk, max_keep=0):
     """sig_sim_select through the C ABI on fp32 features -> (mask int8 [3,B,Lp], raw intra [3,B,Lp], raw inter [B,3,3Lp])."""
     from signal_amd import _lib
     from signal_amd._lib import fill, ref
@@ -102,7 +104,7 @@ def hip_sim_select(dev, sd, patches, cls, topk):
     wk, bk = sd["SIM.token_selection.W_k.weight"].to(dev), sd["SIM.token_selection.W_k.bias"].to(dev)
     bufs = dict(qprime=z(B * 3 * d), cconst=z(B * 3), intra=z(B * 3 * Lp), inter=z(B * 9 * Lp), mask_f=z(3 * B * Lp),
                 mask_u8=torch.zeros(3 * B * Lp, dtype=torch.uint8, device=dev))
-    p = fill(_lib.SigSimParams, sel_wq=wq, sel_bq=bq, sel_wk=wk, sel_bk=bk, topk=topk, dtype=0)
+    p = fill(_lib.SigSimParams, sel_wq=wq, sel_bq=bq, sel_wk=wk, sel_bk=bk, topk=topk, dtype=0, max_keep=max_keep)
     a = fill(_lib.SigSimActs, **bufs)
     _lib.call("sig_sim_select", tokens.data_ptr(), B, L, ref(p), ref(a), torch.cuda.current_stream().cuda_stream)
     mask = bufs["mask_u8"].view(3, B, Lp).cpu().numpy().astype(np.int8)
@@ -129,6 +131,36 @@ def test_sim_select_bit_exact_vs_reference_fixture(dev, golden, tag):
     # raw scores against the oracle's fp32 scores (pre-softmax), to show how much headroom the ranking has
     s_intra = torch.einsum("mbd,mbld->mbl", cls, patches) / np.sqrt(d)
     assert rel_err(intra, s_intra) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["k80_keep75", "k24_keep75"])
+def test_sim_keep_ratio_bit_exact_vs_reference_fixture(dev, golden, tag):
+    """MODEL.FIXED_KEEP_RATIO (useA.py:253-316): exactly int(0.75 * 128) = 96 tokens per modality, both branches -- TOPK 80
+    selects 116..127 (trimmed by the raw intra-modal score), TOPK 24 selects 53..65 (grown) -- bit-exact against the
+    reference's masks; then the same through make_frame / Signal.forward on those features' model."""
+    from tests.golden.make_golden import head_features
+    g = golden(f"g2_sim_{tag}")
+    topk, keep = int(g["topk"]), float(g["keep_ratio"])
+    ocfg = O.rgbnt201_config(topk=topk, keep_ratio=keep)
+    sd = O.init_state_dict(ocfg, seed=int(g["seed_w"]))
+    patches, cls = head_features(ocfg, 8, seed=int(g["seed_x"]))
+    assert g["tie_free"].all()
+    mask, _, _ = hip_sim_select(dev, sd, patches, cls, topk, max_keep=int(128 * keep))
+    assert np.array_equal(mask, g["masks"]), "keep-ratio masks must be bit-exact"
+    assert (mask.sum(-1) == 96).all()
+    before, _, _ = hip_sim_select(dev, sd, patches, cls, topk)
+    assert np.array_equal(before.sum(-1).astype(np.int32), g["count_before"])
+    # the same through the model's SIM stage (config keys MODEL.FIXED_KEEP_RATIO / KEEP_RATIO, make_model.py:107-108)
+    from signal_amd.modeling.hip_engine import SimFn
+    model = build(ocfg, sd, dev, "fp16")
+    model.hip.prepare(dev)
+    tok = torch.cat([cls.unsqueeze(2), patches], dim=2).reshape(-1, 129, 512).contiguous().to(dev)
+    with torch.no_grad():
+        model.hip.grad_mode = False
+        out, m = SimFn.apply(model.hip, 8, tok, *[model.hip.flat.byname[n] for n in model.hip.sim_param_names])
+        model.hip.grad_mode = True
+    assert np.array_equal(m.cpu().numpy().astype(np.int8), g["masks"])
+    assert rel_err(out, torch.from_numpy(g["interact"])) < 1e-3          # fp16 operands: the north_star bar
 
 
 def _kth_gaps(scores64, k):

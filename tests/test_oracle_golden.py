@@ -62,6 +62,26 @@ def test_g2_sim(golden, tag):
     close(out, g["interact"], rtol=1e-3 if sat else 1e-4, atol=2e-4 if sat else 2e-5)
 
 
+@pytest.mark.parametrize("tag", ["k80_keep75", "k24_keep75"])
+def test_g2_sim_keep_ratio(golden, tag):
+    """The exact keep-ratio branch (useA.py:253-316) against the reference: trim (TOPK 80) and grow (TOPK 24)."""
+    g = golden(f"g2_sim_{tag}")
+    topk, keep = int(g["topk"]), float(g["keep_ratio"])
+    cfg = O.rgbnt201_config(topk=topk, keep_ratio=keep)
+    sd = O.init_state_dict(cfg, seed=int(g["seed_w"]))
+    patches, cls = head_features(cfg, 8, seed=int(g["seed_x"]))
+    before, _ = O.sim_select(sd, patches, cls, topk)
+    assert np.array_equal(before.sum(-1).numpy().astype(np.int32), g["count_before"])
+    assert (g["count_before"] > 96).all() if topk == 80 else (g["count_before"] < 96).all()
+    mask, tie_free = O.sim_select(sd, patches, cls, topk, keep)
+    assert tie_free.all() and g["tie_free"].all()
+    assert np.array_equal(mask.numpy().astype(np.int8), g["masks"])
+    assert (mask.sum(-1) == int(128 * keep)).all()
+    out, m2, _ = O.sim_forward(sd, cfg, patches, cls)
+    assert torch.equal(m2, mask)
+    close(out, g["interact"], rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("tag", ["regular", "aligned"])
 def test_g4_gam(golden, tag):
     g = golden(f"g4_gam_{tag}")
