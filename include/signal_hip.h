@@ -35,13 +35,18 @@ int sig_version(void);
  * with HIP events on its own stream, from sig_prof_begin until sig_prof_end; sig_prof_end waits for the
  * recorded events (host-synchronising: call it outside any timed region) and returns the summed kernel
  * time, the number of launches and their algorithmic FLOPs (2*M*N*K each).  epilogue = SIG_PROF_TN256 selects
- * the 256x256 weight-gradient kernel behind sig_gemm_tn instead (N = I, K = J; N = K = 0: every shape). */
+ * the 256x256 weight-gradient kernel behind sig_gemm_tn instead (N = I, K = J; N = K = 0: every shape), and
+ * SIG_PROF_TN_GROUP the grouped weight-gradient kernel (FLOPs = the sum over its jobs). */
 #define SIG_PROF_TN256 100
+#define SIG_PROF_TN_GROUP 101   /* gemm_tn_group_kernel behind sig_gemm_tn_grouped / sig_block_bwd (N = K = 0) */
 int sig_prof_begin(int epilogue, int N, int K, int max_launches);
 int sig_prof_end(double* total_ms, int* launches, double* flops);
 /* Tuning / test aid: pin the row tile of sig_gemm_nt (128, 256 or 320; 0 = choose by the cost estimate) wherever that
  * kernel is legal for the shape; returns the previous setting.  Same as the environment variable SIG_GEMM_TILE. */
 int sig_tune_gemm_tile(int tile);
+/* Same for the weight-gradient path: 128 = the 128x128-tile kernel with f32 atomics, one launch per weight; 256 = the 256x256
+ * kernel, one launch per weight; 0 = default (a block's four weights grouped into one launch).  Environment: SIG_GEMM_TN_TILE. */
+int sig_tune_tn_path(int path);
 /* CUs (0..192) the GEMM launchers leave to concurrent work -- the RCCL channel workgroups that all-reduce gradient buckets
  * under the backward pass (engine/processor.py:212-261 runs DDP's reducer there).  The one-block-per-CU kernels are sized
  * in rounds of the FREE CUs; returns the previous setting.  Environment preset: SIG_RESERVED_CUS. */

@@ -942,8 +942,8 @@ int sig_prof_end_impl(double* total_ms, int* launches, double* flops) {
 }
 
 
-bool sig_prof_tn_start(hipStream_t st, int I, int J) {
-    const bool timed = g_prof.on && g_prof.epi == SIG_PROF_TN256 && (g_prof.N == 0 || (g_prof.N == I && g_prof.K == J)) &&
+bool sig_prof_tn_start(hipStream_t st, int cls, int I, int J) {
+    const bool timed = g_prof.on && g_prof.epi == cls && (g_prof.N == 0 || (g_prof.N == I && g_prof.K == J)) &&
                        g_prof.used + 2 <= g_prof.ev.size();
     if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
     return timed;
@@ -1680,6 +1680,19 @@ float* sig_stream_scratch(hipStream_t st, size_t bytes, int slot) {
 }
 static float* tn_workspace(hipStream_t st, size_t bytes) { return sig_stream_scratch(st, bytes, 0); }
 
+// SIG_GEMM_TN_TILE=<128|256> / sig_tune_tn_path(): pin the weight-gradient path (tests, A/B runs): 128 = the 128x128 kernel
+// with f32 atomics, one launch per weight; 256 = the 256x256 kernel, one launch per weight; 0 = default (grouped per block)
+static int g_force_tn = -1;
+int sig_tune_tn_path_impl(int path) {
+    const int prev = g_force_tn < 0 ? 0 : g_force_tn;
+    g_force_tn = path;
+    return prev;
+}
+int sig_tn_path() {
+    if (g_force_tn < 0) { const char* e = getenv("SIG_GEMM_TN_TILE"); g_force_tn = e ? atoi(e) : 0; }
+    return g_force_tn;
+}
+
 template <int DT>
 static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {
     SigGemmTN p = p_in;
@@ -1693,8 +1706,8 @@ static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {
         attr_done = true;
     }
     const int ksteps = p.Mr >> 6;
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("SIG_GEMM_TN_TILE"); force = e ? atoi(e) : 0; }
+    if (g_force_tn < 0) { const char* e = getenv("SIG_GEMM_TN_TILE"); g_force_tn = e ? atoi(e) : 0; }
+    const int force = g_force_tn;
     // 256x256 tiles for the large weight gradients (one block per CU, <= 256 blocks); the rest on 128x128 tiles
     const bool can256 = (p.I & 255) == 0 && (p.J & 255) == 0 && (p.I >> 8) * (p.J >> 8) <= 128;
     // (also the small square ones: 768x768 out_proj wgrad 63.7 -> 48.2 us) as long as a row chunk keeps >= 8 K-steps

@@ -2,15 +2,20 @@
 // count (the token rows M).  Reference: the four nn.Linear of a ResidualAttentionBlock, modeling/clip/model.py:172-178
 // (attn.in_proj, attn.out_proj, mlp.c_fc, mlp.c_proj); their weight gradients are what autograd's mm backward computes.
 //
-// Work decomposition ("stream-K" over the contraction): the 256x256 output tiles of all jobs are numbered consecutively
-// (a block of the ViT: 27 + 9 + 36 + 36 = 108 tiles), every tile is `ks` K-steps of 64 token rows long, and the
-// tiles * ks K-steps are cut into `grid` equal contiguous ranges, one per workgroup = one per CU.  A range is shorter than a
-// tile (asserted by the launcher), so a workgroup runs at most two segments (the tail of one tile, the head of the next);
-// each segment's 256x256 partial goes to its own workspace slot in MFMA-fragment order, and tn_group_reduce_kernel adds the
-// 2-4 partials of every tile in a fixed order into dW (deterministic, no atomics).
-// Against one launch per weight with a uniform row split (the round-2 form): the K-loops are 164 K-steps instead of 14-56
-// (prologue, first-stage HBM latency and the 256-KB store tail amortised 3-10x better), every CU gets the same amount of work
-// whatever the tile counts are, partial-tile traffic is 2.4x the size of dW instead of 7-28x, and 4 + 4 launches become 1 + 1.
+// Work decomposition: the 256x256 output tiles of all jobs are numbered consecutively (a block of the ViT: 27 + 9 + 36 + 36 =
+// 108 tiles) and the token rows are cut into `nsplit` equal chunks; a unit = (chunk, tile), numbered CHUNK-MAJOR.  `grid`
+// persistent workgroups (one per CU) take units id, id + grid, id + 2 grid, ...: in every round the 32 workgroups of an XCD
+// hold 32 neighbouring tiles of the SAME row chunk, so they march through the same 64-row slabs of dY and X together and the
+// XCD's L2 serves each slab ~4 times (11 + 3 slabs of 32 KB per K-step for 32 x 64 KB requested).  Each unit's 256x256
+// partial goes to its own workspace slot in MFMA-fragment order and tn_group_reduce_kernel adds the chunks of every tile in
+// a fixed order into dW (deterministic, no atomics).  nsplit is chosen so that the rounds are full: B = 64 -> 7 chunks x 108
+// tiles = 756 units = 2.95 rounds of 256 CUs.
+// (A first form cut the tile-major K-step sequence into one contiguous range per CU -- classic stream-K, 164 K-steps per CU,
+// 2.4 partials per tile.  Measured 338 us against 322 + 59 for the four separate launches: workgroups that share a panel sat at
+// unrelated row offsets, nothing was shared in L2 and the kernel streamed 2.75 GB = 8.1 TB/s.  Row-synchronous rounds it is.)
+// Against one launch per weight (the round-2 form): out_proj's 9 tiles no longer need 28 row chunks of 14 K-steps to fill the
+// chip, no launch has a ragged last round of its own, a unit's store tail overlaps the next unit's first loads, and 4 + 4
+// launches become 1 + 1.
 //
 // The main loop is gemm_tn256x16_kernel's (gemm_bf16.hip): 8 waves x (128 x 64) as 8 x 4 mfma_f32_16x16x32, operands
 // row-major over M staged by LDS-DMA (2 x 64 KB stages), read with pairs of ds_read_b64_tr_b16, 4 phases per K-step with
@@ -19,23 +24,13 @@
 
 #include "sig_kernels.h"
 
-#define TNG_MIN 8   // a segment shorter than this many K-steps is given to the neighbouring workgroup (range ends snap to tile edges)
-
 struct SigTnGroup {
     SigTnJob job[SIG_TN_MAX_JOBS];
     int tile0[SIG_TN_MAX_JOBS + 1];   // first tile of each job; tile0[njobs] = tiles
     int njobs, tiles, ks, grid;
-    float* ws;                        // [2 * grid] slots of 65536 floats
+    int nsplit, per;                  // row chunks and K-steps per chunk (the last chunk may be shorter)
+    float* ws;                        // [nsplit * tiles] slots of 65536 floats, slot = chunk * tiles + tile
 };
-
-// first K-step (in tile-major numbering) of workgroup c; c = grid gives the total
-__host__ __device__ static inline int tng_start(int c, int total, int grid, int ks) {
-    long long s = (long long)c * total / grid;
-    const int r = (int)(s % ks);
-    if (r && r < TNG_MIN) s -= r;
-    else if (r > ks - TNG_MIN) s += ks - r;
-    return (int)s;
-}
 
 #define TNG_RDTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define TNG_WAITF4(n, f)                                                                                                    \
@@ -53,8 +48,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int total = p.tiles * p.ks;
-    const int u_beg = tng_start(id, total, p.grid, p.ks), u_end = tng_start(id + 1, total, p.grid, p.ks);
+    const int units = p.nsplit * p.tiles;
 
     // transposed-read addressing: lane = 16*G + 4*tq + pp addresses row (8G + tq), columns 4pp.. of a 16-column tile and
     // receives column (4tq + pp) = lane & 15, rows 8G .. 8G+3 (+4 for the second read)
@@ -77,12 +71,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
 
-    int u = u_beg;
 #pragma unroll 1
-    for (int seg = 0; seg < 2 && u < u_end; ++seg) {
-        const int t = u / p.ks, k0 = u - t * p.ks;
-        const int tile_end = (t + 1) * p.ks;
-        const int nk = (u_end < tile_end ? u_end : tile_end) - u;
+    for (int unit = id; unit < units; unit += p.grid) {
+        const int chunk = unit / p.tiles, t = unit - chunk * p.tiles;
+        const int k0 = chunk * p.per;
+        const int nk = (k0 + p.per < p.ks ? k0 + p.per : p.ks) - k0;     // >= 1: the launcher makes every chunk non-empty
         int jb = 0;
 #pragma unroll
         for (int q = 1; q < SIG_TN_MAX_JOBS; ++q)
@@ -205,48 +198,32 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
 
         // partial tile in fragment order: float4 (wave, a, b, lane) = rows i = wi + 16a + 4(lane >> 4) .. +3 of column
         // j = wj + 16b + (lane & 15); one coalesced 1-KB store per MFMA tile and wave
-        f32x4_t* wt = (f32x4_t*)(p.ws + (size_t)(2 * id + seg) * 65536) + (size_t)wave * 32 * 64 + lane;
+        f32x4_t* wt = (f32x4_t*)(p.ws + (size_t)unit * 65536) + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) wt[(a * 4 + b) * 64] = acc[a][b];
-        // (after the last stage-boundary barrier no wave reads LDS any more: the next segment's DMA may start at once)
-        u += nk;
+        // (after the last stage-boundary barrier no wave reads LDS any more: the next unit's DMA may start at once, under
+        //  this unit's stores)
     }
 }
 
-// dW tile t += its partials, in workgroup order.  A block = 16 rows x 64 columns of one tile (the 4 column tiles b of one
+// dW tile t += its row chunks' partials, in chunk order.  A block = 16 rows x 64 columns of one tile (the 4 column tiles b of one
 // (wave, a)); float4 index r of a partial tile = ((wave * 8 + a) * 4 + b) * 64 + lane.
 __global__ __launch_bounds__(256) void tn_group_reduce_kernel(SigTnGroup p) {
     __shared__ float tile[16][68];
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index over all tiles (grid = tiles * 64 exactly)
     const int t = (int)(q >> 14), r = (int)(q & 16383);
     const int lane = r & 63, f = r >> 6, wave = f >> 5, a = (f >> 2) & 7, b = f & 3;
-    const int total = p.tiles * p.ks;
-    const int lo = t * p.ks, hi = lo + p.ks;
-    // first workgroup whose range reaches into the tile
-    int c = (int)((long long)lo * p.grid / total);
-    if (c > 0) --c;
-    while (tng_start(c + 1, total, p.grid, p.ks) <= lo) ++c;
-    const f32x4_t* ws4 = (const f32x4_t*)p.ws + r;
+    const f32x4_t* src = (const f32x4_t*)(p.ws + (size_t)t * 65536) + r;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    // workgroups c, c+1, ... until one begins at or beyond the tile's end; 4 partials requested before any is added
-    // (fixed order: deterministic).  Workgroup cc's partial of THIS tile is its segment 1 if its range began in the tile before.
-    for (bool more = true; more; c += 4) {
-        f32x4_t v[4];
-        bool ok[4];
+    for (int s0 = 0; s0 < p.nsplit; s0 += 8) {       // 8 partial tiles requested before any is added (fixed order: deterministic)
+        f32x4_t v[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int cc = c + k;
-            const int s = cc < p.grid ? tng_start(cc, total, p.grid, p.ks) : hi;
-            const int e = cc < p.grid ? tng_start(cc + 1, total, p.grid, p.ks) : hi;
-            if (s >= hi) more = false;
-            ok[k] = s < hi && e > s;
-            if (ok[k]) v[k] = ws4[(size_t)(2 * cc + (s < lo ? 1 : 0)) * 16384];
-        }
+        for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(s0 + k < p.nsplit ? s0 + k : s0) * p.tiles * 16384];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (ok[k]) acc += v[k];
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < p.nsplit) acc += v[k];
     }
     int jb = 0;
 #pragma unroll
@@ -270,8 +247,8 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(SigTnGroup p) {
     }
 }
 
-// can the grouped kernel take these jobs on `grid` workgroups?  (every output a multiple of 256 x 256, ranges shorter than a tile)
-static bool tng_fits(const SigTnJob* jobs, int njobs, int Mr, int grid, int* tiles_out) {
+// can the grouped kernel take these jobs?  (every output a multiple of 256 x 256)
+static bool tng_fits(const SigTnJob* jobs, int njobs, int Mr, int* tiles_out) {
     if (njobs < 1 || njobs > SIG_TN_MAX_JOBS || Mr <= 0 || (Mr & 63)) return false;
     int tiles = 0;
     for (int k = 0; k < njobs; ++k) {
@@ -280,12 +257,28 @@ static bool tng_fits(const SigTnJob* jobs, int njobs, int Mr, int grid, int* til
         if ((j.ldp & 7) || (j.ldq & 7) || j.ldp < j.I || j.ldq < j.J || j.ldo < j.J) return false;
         tiles += (j.I >> 8) * (j.J >> 8);
     }
-    const int ks = Mr >> 6;
     *tiles_out = tiles;
-    // a range (+ the snaps at both ends) must stay within one tile length so that a workgroup has at most two segments, and be
-    // long enough that a partial-tile store (256 KB) is amortised: short problems keep the per-weight launches
-    const long long R = (long long)tiles * ks / grid;
-    return R + 1 + 2 * TNG_MIN <= ks && R >= 32;
+    return true;
+}
+
+// row chunks: the count whose rounds of the chip cost the fewest K-steps, a unit's prologue + store tail priced at 8 K-steps
+// and the reduce pass at its bytes (nsplit partials of 256 KB per tile at ~5 TB/s against ~1.3 us per K-step).  Measured at
+// B = 64 (108 tiles, 388 K-steps, same box, ms per train step): 2 chunks 20.03 | 7 chunks 20.29 (kernel 244 us vs 251, but the
+// reduce reads 198 MB instead of 57) | 12 chunks 21.0 | four separate launches (round 2) 21.0.
+static int tng_choose_split(int tiles, int ks, int grid) {
+    static int force = -1;      // SIG_TN_SPLIT=<n>: pin the number of row chunks (A/B runs)
+    if (force < 0) { const char* e = getenv("SIG_TN_SPLIT"); force = e ? atoi(e) : 0; }
+    if (force > 0) return force < ks ? force : ks;
+    int best = 1;
+    long long best_cost = -1;
+    for (int s = 1; s <= 32 && s <= ks; ++s) {
+        const int per = sig_ceil_div(ks, s);
+        if (sig_ceil_div(ks, per) != s) continue;                 // would leave an empty chunk
+        const long long rounds = sig_ceil_div(s * tiles, grid);
+        const long long cost = rounds * (per + 8) + (long long)(0.04 * s * tiles);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 template <int DT>
@@ -306,11 +299,15 @@ static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int t
         flops += 2.0 * Mr * jobs[k].I * jobs[k].J;
     }
     for (int k = njobs; k <= SIG_TN_MAX_JOBS; ++k) g.tile0[k] = t0;
-    g.njobs = njobs; g.tiles = tiles; g.ks = Mr >> 6; g.grid = grid;
-    g.ws = sig_stream_scratch(st, (size_t)2 * grid * 65536 * sizeof(float), 0);
+    g.njobs = njobs; g.tiles = tiles; g.ks = Mr >> 6;
+    const int want = tng_choose_split(tiles, g.ks, grid);
+    g.per = sig_ceil_div(g.ks, want);
+    g.nsplit = sig_ceil_div(g.ks, g.per);
+    g.grid = g.nsplit * tiles < grid ? g.nsplit * tiles : grid;
+    g.ws = sig_stream_scratch(st, (size_t)g.nsplit * tiles * 65536 * sizeof(float), 0);
     SIG_CHECK_ARG(g.ws, "gemm_tn_grouped: no workspace for the partial tiles");
-    const bool timed = sig_prof_tn_start(st, njobs == 1 ? jobs[0].I : 0, njobs == 1 ? jobs[0].J : 0);
-    hipLaunchKernelGGL(gemm_tn_group_kernel<DT>, dim3(grid), dim3(512), 131072, st, g);
+    const bool timed = sig_prof_tn_start(st, SIG_PROF_TN_GROUP, 0, 0);
+    hipLaunchKernelGGL(gemm_tn_group_kernel<DT>, dim3(g.grid), dim3(512), 131072, st, g);
     if (timed) sig_prof_tn_stop(st, flops);
     SIG_CHECK_LAUNCH("gemm_tn_group");
     hipLaunchKernelGGL(tn_group_reduce_kernel, dim3(tiles * 64), dim3(256), 0, st, g);
@@ -329,10 +326,10 @@ int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, 
     SIG_CHECK_ARG(jobs && njobs >= 1 && njobs <= SIG_TN_MAX_JOBS, "gemm_tn_grouped: 1..%d jobs", SIG_TN_MAX_JOBS);
     const int grid = sig_free_cus();
     int tiles = 0;
-    if (sig_tn_grouped_enabled() && tng_fits(jobs, njobs, Mr, grid, &tiles))
+    if (sig_tn_grouped_enabled() && sig_tn_path() == 0 && tng_fits(jobs, njobs, Mr, &tiles))
         return dt == SIG_DT_F16 ? launch_group<SIG_DT_F16>(jobs, njobs, Mr, grid, tiles, st)
                                 : launch_group<SIG_DT_BF16>(jobs, njobs, Mr, grid, tiles, st);
-    // shapes the grouped kernel does not take (small batches, outputs that are not multiples of 256): one launch per weight
+    // shapes the grouped kernel does not take (outputs that are not multiples of 256): one launch per weight
     for (int k = 0; k < njobs; ++k) {
         SigGemmTN p{};
         p.P = jobs[k].P; p.Q = jobs[k].Q; p.ldp = jobs[k].ldp; p.ldq = jobs[k].ldq; p.Mr = Mr; p.I = jobs[k].I; p.J = jobs[k].J;

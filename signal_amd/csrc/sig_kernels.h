@@ -40,6 +40,8 @@ int sig_prof_begin_impl(int epi, int N, int K, int max_launches);
 int sig_prof_end_impl(double* total_ms, int* launches, double* flops);
 int sig_tune_gemm_tile_impl(int tile);
 int sig_tune_reserved_cus_impl(int n);
+int sig_tune_tn_path_impl(int path);
+int sig_tn_path();
 
 struct SigGemmTN {
     const bf16_t* P;  // [Mr, ldp], columns I
@@ -64,7 +66,10 @@ struct SigTnJob {
 };
 int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, hipStream_t st);
 int sig_free_cus();                                            // 256 minus the CUs reserved for RCCL (sig_tune_reserved_cus)
-bool sig_prof_tn_start(hipStream_t st, int I, int J);          // bench.py's roofline leg (class SIG_PROF_TN256)
+#ifndef SIG_PROF_TN_GROUP
+#define SIG_PROF_TN_GROUP 101   // sig_prof_begin class: gemm_tn_group_kernel launches (a block's four weight gradients)
+#endif
+bool sig_prof_tn_start(hipStream_t st, int cls, int I, int J);   // bench.py's roofline leg
 void sig_prof_tn_stop(hipStream_t st, double flops);
 // library-owned scratch per (device, stream, slot): nullptr when it cannot be had (callers then fall back to atomics)
 float* sig_stream_scratch(hipStream_t st, size_t bytes, int slot);

@@ -408,8 +408,9 @@ def test_gemm_tn_grouped_block_shapes_vs_fp64(dev, dt16, mr, reserved):
         lib.sig_tune_reserved_cus(prev)
 
 
-def test_gemm_tn_grouped_falls_back_on_small_problems(dev):
-    """B = 8 (3 200 rows) and outputs that are not multiples of 256 take the per-weight launches: same results."""
+def test_gemm_tn_grouped_small_batch_and_fallback(dev):
+    """B = 8 (3 200 rows: two row chunks, one round) through the grouped kernel, and a group with an output that is not a
+    multiple of 256 (falls back to one launch per weight): same results."""
     ops = _ops()
     g = torch.Generator(device="cpu").manual_seed(3)
     mr = 3200
@@ -418,3 +419,10 @@ def test_gemm_tn_grouped_falls_back_on_small_problems(dev):
     o1, o2 = torch.zeros(2304, 768, device=dev), torch.zeros(384, 128, device=dev)
     ops.gemm_tn_grouped([(p1, q1, o1), (p2, q2, o2)])
     assert rel_err(o1, p1.double().t() @ q1.double()) < 5e-6 and rel_err(o2, p2.double().t() @ q2.double()) < 5e-6
+    o3 = torch.zeros(2304, 768, device=dev)
+    ops.gemm_tn_grouped([(p1, q1, o3)])                   # multiples of 256: the grouped kernel itself
+    assert rel_err(o3, p1.double().t() @ q1.double()) < 5e-6
+    for mr2 in (64, 128, 448):                            # fewer K-steps than chunks would like
+        o4 = torch.zeros(2304, 768, device=dev)
+        ops.gemm_tn_grouped([(p1[:mr2], q1[:mr2], o4)])
+        assert rel_err(o4, p1[:mr2].double().t() @ q1[:mr2].double()) < 5e-6, mr2
