@@ -225,6 +225,22 @@ int sig_head_bwd(const SigVitDims* d, const SigHeadParams* p, const SigHeadActs*
                  void* stream);
 
 /* ================================================================================================
+ * K18 -- the path's one exchange step: SUM all-reduce of gradient ranges over RCCL (xGMI) on a side HIP stream,
+ * overlapped with the backward.  Replaces DistributedDataParallel's gradient reduction (engine/processor.py:100-105).
+ * RCCL is bound at run time (dlopen librccl.so.1), so a process that already carries PyTorch's RCCL keeps using that copy.
+ *   rank 0: sig_comm_unique_id(id) -> ship the 128 bytes to the other ranks (any channel) -> every rank: sig_comm_init
+ *   per bucket: sig_comm_allreduce_async(c, grad + lo, hi - lo, compute_stream)  [right after the bucket's backward is enqueued]
+ *   before the optimizer: sig_comm_wait(c, compute_stream)                        [device-side wait, no host sync]
+ * The average (1 / world) is the caller's (sig_adam_step's grad_scale).
+ * ================================================================================================ */
+typedef struct SigComm SigComm;
+int sig_comm_unique_id(void* id128 /* out: 128 bytes */);
+int sig_comm_init(SigComm** comm, int rank, int world, const void* id128);
+int sig_comm_allreduce_async(SigComm* comm, float* buf, size_t count, void* compute_stream);
+int sig_comm_wait(SigComm* comm, void* stream);
+int sig_comm_destroy(SigComm* comm);
+
+/* ================================================================================================
  * SIM -- Select_Interactive_Module (modeling/AddModule/useA.py:426-476), on the projected tokens
  * tokens f32 [S*L padded, 512] (row s*L = CLS of sequence s = modality*B + b, rows s*L+1.. = patches).
  * ================================================================================================ */

@@ -23,6 +23,11 @@ SIGNATURES = {
     "sig_gemm_nt": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "sig_gemm_tn": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "sig_gemm_tn_grouped": [_vp, _i, _i, _i, _vp],
+    "sig_comm_unique_id": [_vp],
+    "sig_comm_init": [_vp, _i, _i, _vp],
+    "sig_comm_allreduce_async": [_vp, _vp, _sz, _vp],
+    "sig_comm_wait": [_vp, _vp],
+    "sig_comm_destroy": [_vp],
     "sig_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
     "sig_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sig_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

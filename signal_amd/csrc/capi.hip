@@ -57,6 +57,14 @@ int sig_gemm_tn_grouped(const SigTnJobDesc* jobs, int n, int Mr, int dtype, void
     return sig_launch_gemm_tn_grouped(j, n, Mr, dtype, (hipStream_t)stream);
 }
 
+int sig_comm_unique_id(void* id128) { return sig_comm_unique_id_impl(id128); }
+int sig_comm_init(SigComm** comm, int rank, int world, const void* id128) { return sig_comm_init_impl(comm, rank, world, id128); }
+int sig_comm_allreduce_async(SigComm* comm, float* buf, size_t count, void* compute_stream) {
+    return sig_comm_allreduce_async_impl(comm, buf, count, (hipStream_t)compute_stream);
+}
+int sig_comm_wait(SigComm* comm, void* stream) { return sig_comm_wait_impl(comm, (hipStream_t)stream); }
+int sig_comm_destroy(SigComm* comm) { return sig_comm_destroy_impl(comm); }
+
 int sig_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y_bf16, float* y_f32, float* mean,
                       float* rstd, int M, int D, float eps, int dtype, void* stream) {
     return sig_launch_layernorm_fwd(x, gamma, beta, y_bf16, y_f32, mean, rstd, M, D, eps, dtype, (hipStream_t)stream);

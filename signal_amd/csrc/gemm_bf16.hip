@@ -901,6 +901,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt320_kernel(SigGemmNT p, int mp)
 }
 
 // ---- live timing of one GEMM shape (bench.py's roofline leg): HIP events on the launch stream ----
+#include <atomic>
 #include <vector>
 static struct {
     bool on = false;
@@ -970,7 +971,8 @@ static int choose_band(int tn, int K, int BN) {
 // under the backward pass its channel workgroups hold CUs for milliseconds (a GEMM block's 8 waves x 256 registers cannot
 // share a CU with them), so the trainer reserves CUs for that phase (sig_tune_reserved_cus; SIG_RESERVED_CUS presets it)
 // and the tile choice and the wgrad's row split are made for the rest.
-static int g_reserved_cus = -1;
+// (atomic: set from the training thread around the backward, read by launch_nt / launch_tn on autograd's device thread)
+static std::atomic<int> g_reserved_cus{-1};
 static int free_cus() {
     if (g_reserved_cus < 0) { const char* e = getenv("SIG_RESERVED_CUS"); g_reserved_cus = e ? atoi(e) : 0; }
     const int f = 256 - g_reserved_cus;
@@ -978,15 +980,15 @@ static int free_cus() {
 }
 int sig_free_cus() { return free_cus(); }
 int sig_tune_reserved_cus_impl(int n) {
-    const int prev = g_reserved_cus < 0 ? 0 : g_reserved_cus;
+    const int cur = g_reserved_cus, prev = cur < 0 ? 0 : cur;
     g_reserved_cus = n < 0 ? 0 : (n > 192 ? 192 : n);
     return prev;
 }
 
 // SIG_GEMM_TILE=<128|256|320> / sig_tune_gemm_tile(): pin the NT tile wherever that kernel is legal (tests, A/B runs)
-static int g_force_tile = -1;
+static std::atomic<int> g_force_tile{-1};
 int sig_tune_gemm_tile_impl(int tile) {
-    const int prev = g_force_tile < 0 ? 0 : g_force_tile;
+    const int cur = g_force_tile, prev = cur < 0 ? 0 : cur;
     g_force_tile = tile;
     return prev;
 }
@@ -1682,9 +1684,9 @@ static float* tn_workspace(hipStream_t st, size_t bytes) { return sig_stream_scr
 
 // SIG_GEMM_TN_TILE=<128|256> / sig_tune_tn_path(): pin the weight-gradient path (tests, A/B runs): 128 = the 128x128 kernel
 // with f32 atomics, one launch per weight; 256 = the 256x256 kernel, one launch per weight; 0 = default (grouped per block)
-static int g_force_tn = -1;
+static std::atomic<int> g_force_tn{-1};
 int sig_tune_tn_path_impl(int path) {
-    const int prev = g_force_tn < 0 ? 0 : g_force_tn;
+    const int cur = g_force_tn, prev = cur < 0 ? 0 : cur;
     g_force_tn = path;
     return prev;
 }

@@ -144,3 +144,11 @@ int sig_launch_bnneck_bwd(const float* x, const float* y, const float* bn_w, con
 int sig_launch_reid_loss(const float* logits, const float* feat, const int64_t* target, int B, int F, int C, float eps, float w_id,
                          float w_tri, float margin, const float* upstream, float* loss, float* dlogits, float* gram, int* pidx, int* nidx,
                          float* coef, float* dfeat, hipStream_t st);
+
+// ---- collective (comm.hip) -------------------------------------------------------------------------------------
+struct SigComm;
+int sig_comm_unique_id_impl(void* id128);
+int sig_comm_init_impl(SigComm** out, int rank, int world, const void* id128);
+int sig_comm_allreduce_async_impl(SigComm* c, float* buf, size_t count, hipStream_t compute_stream);
+int sig_comm_wait_impl(SigComm* c, hipStream_t stream);
+int sig_comm_destroy_impl(SigComm* c);

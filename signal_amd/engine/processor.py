@@ -17,7 +17,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from ..utils.metrics import R1_mAP_eval
+from ..utils.metrics import R1_mAP, R1_mAP_eval, make_evaluator
 from .trainer import TrainStep
 
 
@@ -54,7 +54,7 @@ def do_train(cfg, model, center_criterion, train_loader, val_loader, optimizer, 
     engine = TrainStep(cfg, model, num_classes=model.num_classes, world_size=world, loss_fn=loss_fn, optimizer=optimizer,
                        stage=stage)
     loss_meter, acc_meter = AverageMeter(), AverageMeter()
-    evaluator = R1_mAP_eval(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM)
+    evaluator = make_evaluator(cfg, num_query)          # MSVR310: the scene protocol (processor.py:112-116)
     best = {"mAP": 0.0, "Rank-1": 0.0, "Rank-5": 0.0, "Rank-10": 0.0}
     out_dir = os.path.join(cfg.OUTPUT_DIR, cfg.ckpt_save_path)
     os.makedirs(out_dir, exist_ok=True)
@@ -105,7 +105,10 @@ def _run_eval(model, val_loader, device, evaluator, sge):
         with torch.no_grad():
             feat = model(_to_dev(img, device), cam_label=camids.to(device), view_label=target_view.to(device),
                          training=False, sge=sge)
-        evaluator.update((feat, pid, camid))
+        if isinstance(evaluator, R1_mAP):               # MSVR310: the view label carries the scene id (processor.py:421,430-433)
+            evaluator.update((feat, pid, camid, target_view))
+        else:
+            evaluator.update((feat, pid, camid))
     cmc, mAP = evaluator.compute()[:2]
     return cmc, mAP
 
@@ -126,7 +129,7 @@ def do_inference(cfg, model, val_loader, num_query, logger, sge, local_rank):
     device = torch.device(f"cuda:{local_rank}")
     logger = logging.getLogger("Signal.test")
     logger.info("Enter inferencing")
-    evaluator = R1_mAP_eval(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM)
+    evaluator = make_evaluator(cfg, num_query)          # processor.py:385-389
     model.to(device)
     cmc, mAP = _run_eval(model, val_loader, device, evaluator, sge)
     logger.info("Validation Results ")

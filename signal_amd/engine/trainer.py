@@ -79,16 +79,28 @@ class TrainStep:
         self.reducer = None
         # CUs left to RCCL's channel workgroups while the gradient buckets are all-reduced under the backward pass: the
         # one-block-per-CU GEMMs are sized in rounds of the free CUs (include/signal_hip.h, sig_tune_reserved_cus)
+        # Default 16 with an nccl (= RCCL) group, 0 otherwise; SIGNAL_RESERVED_CUS forces a value with any backend (the
+        # gloo tests use it to run the backward with the re-sized tiles and grids).  Sizing for 240 CUs costs a single GPU
+        # +0.3 % (measured); not reserving costs a second round on every 234-tile GEMM that meets a bucket in flight.
+        # UNMEASURED against real RCCL traffic (no multi-GPU box this round or the last).
         self.reserved_cus = 0
-        if world_size > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
-            self.reserved_cus = int(os.environ.get("SIGNAL_RESERVED_CUS", "16"))
+        if world_size > 1 and torch.distributed.is_initialized():
+            env = os.environ.get("SIGNAL_RESERVED_CUS")
+            if env is not None:
+                self.reserved_cus = int(env)
+            elif torch.distributed.get_backend() == "nccl":
+                self.reserved_cus = 16
+        if self.reserved_cus and not hasattr(_lib.load(), "sig_tune_reserved_cus"):
+            self.reserved_cus = 0          # an older library without the tuning exports (_lib._TUNING_ONLY): nothing to size
         if world_size > 1:
             fl = hip.flat
             sizes = {n: fl.byname[n].numel() for n in fl.names}
             blocks, _ = plan_buckets(fl.names, fl.offsets, sizes, fl.total, skip=self.inactive)
-            early, late = split_rest(fl.names, fl.offsets, sizes, skip=self.inactive)
+            early, late = split_rest(fl.names, fl.offsets, sizes, skip=self.inactive, late_names=hip.embed_param_names)
             self.reducer = GradReducer(fl.grad, blocks, late, rest_early=early)
-            self.reducer.broadcast_params(fl.data)      # DDP's construction-time broadcast from rank 0
+            self.reducer.broadcast_params(fl.data)      # DDP's construction-time broadcast from rank 0 (parameters ...
+            self._buffers = [b for _, b in model.named_buffers()]
+            self.reducer.broadcast_buffers(self._buffers)   # ... and buffers)
             hip._pack()
             hip.on_block_grads_ready = self.reducer.on_block_ready
             hip.on_head_grads_ready = self.reducer.on_head_ready
@@ -104,6 +116,8 @@ class TrainStep:
     def step(self, img, target, target_cam, target_view=None):
         hip = self.model.hip
         hip.flat.grad.zero_()
+        if self.reducer is not None:
+            self.reducer.broadcast_buffers(self._buffers)    # DDP broadcast_buffers: rank 0's BN running statistics, every forward
         out = self.model(img, label=target, cam_label=target_cam, view_label=target_view, training=True, sge=self.stage)
         loss = total_loss(self.cfg, out, self.loss_fn, target, target_cam, self.stage)
         if self.reserved_cus:

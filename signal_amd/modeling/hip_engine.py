@@ -235,6 +235,10 @@ class HipPath:
                             positional_embedding=self._g(base + "positional_embedding"),
                             cv_embed=self._g(cv) if cv else None, ln_w=self._g(base + "ln_pre.weight"),
                             ln_b=self._g(base + "ln_pre.bias"))
+        # what sig_embed_bwd writes: the only gradients that are not final before the last stage of the backward (the
+        # data-parallel reducer sends everything else earlier)
+        self.embed_param_names = [base + "conv1.weight", base + "class_embedding", base + "positional_embedding",
+                                  base + "ln_pre.weight", base + "ln_pre.bias"] + ([cv] if cv else [])
         self.block_p, self.block_g = [], []
         for i in range(self.layers):
             p = f"{base}transformer.resblocks.{i}."

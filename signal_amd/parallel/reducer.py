@@ -23,14 +23,18 @@ def embedding_side(name: str) -> bool:
                           "base.ln_pre.weight", "base.ln_pre.bias"))
 
 
-def split_rest(names: Sequence[str], offsets: Dict[str, int], sizes: Dict[str, int], skip: Callable[[str], bool] = lambda n: False):
-    """-> (early, late): ranges of the non-block, non-skipped parameters, split by embedding_side()."""
+def split_rest(names: Sequence[str], offsets: Dict[str, int], sizes: Dict[str, int], skip: Callable[[str], bool] = lambda n: False,
+               late_names=None):
+    """-> (early, late): ranges of the non-block, non-skipped parameters.  late = the parameters whose gradient the LAST stage
+    of the backward writes: `late_names` (the engine's own list of what sig_embed_bwd is bound to, HipPath.embed_param_names)
+    or, without it, embedding_side()'s name rule."""
     pad = lambda n: (n + 63) // 64 * 64
+    is_late = embedding_side if late_names is None else set(late_names).__contains__
     out: Dict[bool, List[Tuple[int, int]]] = {False: [], True: []}
     for n in names:
         if ".transformer.resblocks." in n or skip(n):
             continue
-        lst, lo, hi = out[embedding_side(n)], offsets[n], offsets[n] + pad(sizes[n])
+        lst, lo, hi = out[bool(is_late(n))], offsets[n], offsets[n] + pad(sizes[n])
         if lst and lst[-1][1] == lo:
             lst[-1] = (lst[-1][0], hi)
         else:
@@ -108,3 +112,22 @@ class GradReducer:
         """Initial parameter sync (DDP construction broadcast)."""
         if self.world > 1:
             dist.broadcast(flat_data, src=src, group=self.group)
+
+    def broadcast_buffers(self, buffers: Sequence[torch.Tensor], src: int = 0):
+        """DistributedDataParallel(broadcast_buffers=True), the reference's wrapper (engine/processor.py:100-105): module
+        buffers -- here the BNNecks' running_mean / running_var / num_batches_tracked -- are overwritten by rank `src`'s at
+        construction and at the start of EVERY forward, so every rank carries rank 0's running statistics (they never enter
+        the training loss; a checkpoint or an in-training evaluation on any rank then reads the same numbers).  The float
+        buffers travel as one flat tensor, the integer counters as another: two small broadcasts per step."""
+        if self.world == 1:
+            return
+        for kind in (True, False):
+            grp = [b for b in buffers if b.is_floating_point() == kind and b.numel()]
+            if not grp:
+                continue
+            flat = torch.cat([b.reshape(-1) for b in grp])
+            dist.broadcast(flat, src=src, group=self.group)
+            off = 0
+            for b in grp:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()

@@ -1,5 +1,6 @@
 """Retrieval metrics of the evaluation loop (utils/metrics.py:111-170,222-300,494-500 of the reference):
-market1501-style CMC / mAP where, per query, gallery images of the same identity AND camera are discarded.
+market1501-style CMC / mAP where, per query, gallery images of the same identity AND camera are discarded (R1_mAP_eval), and
+the MSVR310 variant that discards same identity AND scene (R1_mAP / eval_func_msrv, utils/metrics.py:13-109,174-218).
 
 The feature work runs on the GPU: features stay in HBM as they arrive, L2 normalisation is one torch op, and the
 distance matrix |q|^2 + |g|^2 - 2 q.g^T -- the reference's `addmm_` (utils/metrics.py:494-500) -- is formed by the hand-
@@ -58,14 +59,11 @@ def euclidean_distance(qf: torch.Tensor, gf: torch.Tensor) -> torch.Tensor:
     return qf.pow(2).sum(1, keepdim=True) + gf.pow(2).sum(1, keepdim=True).t() - 2.0 * gram_f32(qf, gf)
 
 
-def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, order=None):
-    """CMC curve and mAP (utils/metrics.py:111-170).  `order` = precomputed argsort of distmat rows (device-side sort).
-
-    One deliberate difference: when fewer than max_rank gallery items survive a query's same-id-same-camera filter its CMC
-    row is shorter than the others; the reference then builds a ragged `np.asarray(all_cmc)` (metrics.py:151,167) and fails.
-    Here a short row is extended with its last value (a match once found stays found), which is what the curve means."""
+def _cmc_map(distmat, q_pids, g_pids, q_tags, g_tags, max_rank, order):
+    """CMC curve and mAP where, per query, the gallery items with the query's identity AND the query's tag (camera id or scene
+    id) are discarded."""
     distmat = np.asarray(distmat)
-    q_pids, g_pids, q_camids, g_camids = (np.asarray(a) for a in (q_pids, g_pids, q_camids, g_camids))
+    q_pids, g_pids, q_tags, g_tags = (np.asarray(a) for a in (q_pids, g_pids, q_tags, g_tags))
     num_q, num_g = distmat.shape
     if num_g < max_rank:
         max_rank = num_g
@@ -75,7 +73,7 @@ def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, order=No
     all_cmc, all_ap = [], []
     for q in range(num_q):
         o = order[q]
-        keep = ~((g_pids[o] == q_pids[q]) & (g_camids[o] == q_camids[q]))
+        keep = ~((g_pids[o] == q_pids[q]) & (g_tags[o] == q_tags[q]))
         m = (g_pids[o] == q_pids[q])[keep].astype(np.int32)
         if not m.any():
             continue
@@ -90,6 +88,23 @@ def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, order=No
         cmc[: c.size] += c
         cmc[c.size:] += c[-1]
     return cmc / len(all_ap), float(np.mean(all_ap))
+
+
+def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, order=None):
+    """CMC curve and mAP (utils/metrics.py:111-170): same identity AND same camera are discarded.  `order` = precomputed
+    argsort of distmat rows (device-side sort).
+
+    One deliberate difference: when fewer than max_rank gallery items survive a query's filter its CMC row is shorter than
+    the others; the reference then builds a ragged `np.asarray(all_cmc)` (metrics.py:151,167) and fails.  Here a short row is
+    extended with its last value (a match once found stays found), which is what the curve means."""
+    return _cmc_map(distmat, q_pids, g_pids, q_camids, g_camids, max_rank, order)
+
+
+def eval_func_msrv(distmat, q_pids, g_pids, q_camids, g_camids, q_sceneids, g_sceneids, max_rank=50, order=None):
+    """The MSVR310 protocol (utils/metrics.py:13-109): per query, gallery items of the same identity from the same SCENE are
+    discarded (`remove = (g_pids == q_pid) & (g_sceneids == q_sceneid)`, metrics.py:66); camera ids do not enter.  The
+    reference's side effect of writing a rank list to ./re.txt (metrics.py:38-39,69-76) is intentionally absent."""
+    return _cmc_map(distmat, q_pids, g_pids, q_sceneids, g_sceneids, max_rank, order)
 
 
 class R1_mAP_eval:
@@ -126,3 +141,44 @@ class R1_mAP_eval:
         distmat = dist.cpu().numpy()
         cmc, mAP = eval_func(distmat, q_pids, g_pids, q_cam, g_cam, self.max_rank, order=order)
         return cmc, mAP, distmat, self.pids, self.camids, qf, gf
+
+
+class R1_mAP(R1_mAP_eval):
+    """utils/metrics.py:174-218, the MSVR310 evaluator: update((feat, pid, camid, sceneid[, img_paths])), ranking by
+    eval_func_msrv (same identity AND same scene discarded).  Unlike R1_mAP_eval the reference compares feat_norm with the
+    string 'yes' here (metrics.py:197), so TEST.FEAT_NORM = 'no' really skips the normalisation."""
+
+    def reset(self):
+        super().reset()
+        self.sceneids = []
+
+    def update(self, output):
+        feat, pid, camid, sceneid = output[0], output[1], output[2], output[3]
+        self.feats.append(feat.detach().float())
+        self.pids.extend(np.asarray(pid).tolist())
+        self.camids.extend(np.asarray(camid).tolist())
+        self.sceneids.extend(np.asarray(sceneid).tolist())
+        if len(output) > 4:
+            self.img_paths.extend(output[4])
+
+    def compute(self):
+        feats = torch.cat(self.feats, dim=0)
+        if self.feat_norm == "yes" or self.feat_norm is True:
+            feats = torch.nn.functional.normalize(feats, dim=1, p=2)
+        nq = self.num_query
+        qf, gf = feats[:nq], feats[nq:]
+        q_pids, g_pids = np.asarray(self.pids[:nq]), np.asarray(self.pids[nq:])
+        q_cam, g_cam = np.asarray(self.camids[:nq]), np.asarray(self.camids[nq:])
+        q_sc, g_sc = np.asarray(self.sceneids[:nq]), np.asarray(self.sceneids[nq:])
+        dist = euclidean_distance(qf, gf)
+        order = torch.argsort(dist, dim=1, stable=True).cpu().numpy()
+        distmat = dist.cpu().numpy()
+        cmc, mAP = eval_func_msrv(distmat, q_pids, g_pids, q_cam, g_cam, q_sc, g_sc, self.max_rank, order=order)
+        return cmc, mAP, distmat, self.pids, self.camids, qf, gf
+
+
+def make_evaluator(cfg, num_query):
+    """engine/processor.py:112-116,385-389: MSVR310 is scored under its scene protocol, everything else under the camera one."""
+    if cfg.DATASETS.NAMES == "MSVR310":
+        return R1_mAP(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM)
+    return R1_mAP_eval(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM)

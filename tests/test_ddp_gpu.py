@@ -29,18 +29,36 @@ model = build(ocfg, sd, dev)
 cfg = model.cfg
 cfg.SOLVER.OPTIMIZER_NAME = "Adam"; cfg.SOLVER.BASE_LR = 3.5e-4
 ts = TrainStep(cfg, model, num_classes=ocfg.num_classes, world_size=world)
+# SIGNAL_RESERVED_CUS (set by the test) sizes the backward's tiles and grids for 240 CUs even under gloo
+assert ts.reserved_cus == int(os.environ.get("SIGNAL_RESERVED_CUS", "0")), ts.reserved_cus
+if os.environ.get("SIGNAL_LATE_EVERYTHING") == "1":      # move the head-side remainder into the end-of-backward group
+    ts.reducer.rest = sorted(ts.reducer.rest_early + ts.reducer.rest)
+    ts.reducer.rest_early = []
+# DDP's buffer broadcast: perturb this rank's BN running statistics, the step must restore rank 0's before the forward
+if rank == 1:
+    model.bottleneck.running_mean.add_(3.0)
 img, vid, cam = O.synthetic_batch(ocfg, 4, seed=500 + rank)
 img = {k: v.to(dev) for k, v in img.items()}
+_fwd = model.forward
+def spy(*a, **k):            # what the forward sees: the buffers after DDP's per-forward broadcast
+    ts.bn_mean_seen = model.bottleneck.running_mean.clone()
+    return _fwd(*a, **k)
+model.forward = spy
 loss = ts.step(img, vid.to(dev), cam.to(dev))
 torch.cuda.synchronize()
-out = {"grad": model.hip.flat.grad.cpu(), "param": model.hip.flat.data.cpu(), "loss": float(loss)}
+out = {"grad": model.hip.flat.grad.cpu(), "param": model.hip.flat.data.cpu(), "loss": float(loss),
+       "bn_mean_before": ts.bn_mean_seen.cpu()}
 torch.save(out, sys.argv[3] + f"/rank{rank}.pt")
 dist.destroy_process_group()
 print("ok", rank)
 '''
 
 
-def test_two_rank_train_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize("reserved,late_all", [("16", "0"), ("0", "1")])
+def test_two_rank_train_step_matches_single_process(tmp_path, reserved, late_all):
+    """reserved = 16: the backward runs with the tile choice and grids sized for 240 CUs (what an nccl group gets by default);
+    late_all = 1: every non-block bucket is sent at the end of the backward instead of right after the head stage -- the early
+    issue must not change a single bit (it is only legal because every head-side gradient is final by then)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     script = tmp_path / "worker.py"
@@ -50,7 +68,8 @@ def test_two_rank_train_step_matches_single_process(tmp_path):
         port = str(sk.getsockname()[1])
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", SIGNAL_RESERVED_CUS=reserved,
+                   SIGNAL_LATE_EVERYTHING=late_all)
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT, port, str(tmp_path)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -66,6 +85,8 @@ def test_two_rank_train_step_matches_single_process(tmp_path):
     # both ranks hold the same summed gradient and the same updated parameters
     assert torch.equal(r0["grad"], r1["grad"])
     assert torch.equal(r0["param"], r1["param"])
+    # rank 1's perturbed BN running mean was overwritten by rank 0's before its forward (DDP broadcast_buffers)
+    assert torch.equal(r0["bn_mean_before"], r1["bn_mean_before"])
 
     # single-process reference: rank-0 weights, both ranks' batches, gradients summed by hand
     from oracle import signal_ref as O
@@ -93,3 +114,41 @@ def test_two_rank_train_step_matches_single_process(tmp_path):
     err = float((r0["grad"] - want).norm() / want.norm())
     assert err < 5e-6, err
     assert float((r0["param"] - grads[0] * 0).abs().sum()) > 0
+
+
+def test_sig_comm_exports_run_over_rccl_with_one_rank():
+    """K18 through the C ABI (include/signal_hip.h: sig_comm_*): RCCL is bound at run time, a one-rank communicator is
+    created from a unique id, two gradient ranges are all-reduced on the communicator's side stream behind kernels that are
+    still running on the compute stream, and the compute stream waits for them on the device.  One GPU = one rank (RCCL
+    needs a device per rank), so the SUM over ranks is the identity here: what is checked is the binding, the stream
+    ordering (the all-reduce must see the values written by the kernels enqueued before it) and that nothing else moves.
+    More ranks: unmeasured (no multi-GPU box)."""
+    import ctypes
+    from signal_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    _lib.load()
+    uid = ctypes.create_string_buffer(128)
+    _lib.call("sig_comm_unique_id", ctypes.cast(uid, ctypes.c_void_p))
+    assert any(uid.raw)
+    comm = ctypes.c_void_p()
+    _lib.call("sig_comm_init", ctypes.cast(ctypes.byref(comm), ctypes.c_void_p), 0, 1, ctypes.cast(uid, ctypes.c_void_p))
+    assert comm.value
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        g = torch.zeros(1 << 22, device=dev)
+        big = torch.randn(4096, 4096, device=dev)
+        for _ in range(3):                       # keep the compute stream busy, then produce the "gradients"
+            big = big @ big * 1e-3
+        g[: 1 << 20] = 2.0
+        _lib.call("sig_comm_allreduce_async", comm, g.data_ptr(), 1 << 20, st)
+        g[1 << 20: 1 << 21] = 3.0
+        _lib.call("sig_comm_allreduce_async", comm, g.data_ptr() + 4 * (1 << 20), 1 << 20, st)
+        _lib.call("sig_comm_wait", comm, st)
+        total = g.sum()                          # enqueued behind the wait on the compute stream
+        torch.cuda.synchronize()
+        assert float(total) == 2.0 * (1 << 20) + 3.0 * (1 << 20)
+        assert float(g[1 << 21:].abs().max()) == 0.0
+    finally:
+        _lib.call("sig_comm_destroy", comm)

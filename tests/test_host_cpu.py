@@ -201,6 +201,51 @@ def test_bucket_plan_covers_the_flat_buffer():
     assert all(a[1] <= b[0] for a, b in zip(both, both[1:]))
 
 
+def test_backward_hook_order_issues_buckets_in_reverse_block_order():
+    """Replays the hook sequence of one ViT backward (signal_amd/modeling/hip_engine.py::vit_backward: head hook, then the
+    blocks 11..0, then finish()) on the real parameter layout and records what the reducer would send and when: the
+    head-side remainder goes first (under all twelve blocks), block buckets follow in reverse block order, each exactly one
+    block's contiguous 28 MB, and only the ~3 MB embedding group is issued after the last block."""
+    from signal_amd.parallel.reducer import GradReducer, plan_buckets, split_rest
+    ocfg = O.rgbnt201_config()
+    sd = O.init_state_dict(ocfg, seed=1)
+    names = [k for k in sd if "running_" not in k]
+    sizes = {n: sd[n].numel() for n in names}
+    pad = lambda n: (n + 63) // 64 * 64
+    offsets, off = {}, 0
+    for n in names:
+        offsets[n] = off
+        off += pad(sizes[n])
+    skip = lambda n: n.startswith("SIM.token_selection.")
+    base = "clip_vision_encoder.base."
+    embed = [base + "conv1.weight", base + "class_embedding", base + "positional_embedding", base + "ln_pre.weight",
+             base + "ln_pre.bias", "clip_vision_encoder.cv_embed"]          # = HipPath.embed_param_names
+    blocks, _ = plan_buckets(names, offsets, sizes, off, skip=skip)
+    early, late = split_rest(names, offsets, sizes, skip=skip, late_names=embed)
+    assert (early, late) == split_rest(names, offsets, sizes, skip=skip)     # the engine's list and the name rule agree today
+    red = GradReducer(torch.zeros(1), blocks, late, rest_early=early)
+    red.world = 2                                   # pretend: record instead of communicating
+    sent = []
+    red._reduce = lambda lo, hi: sent.append((lo, hi))
+    red.on_head_ready()
+    n_head = len(sent)
+    for layer in reversed(range(12)):
+        red.on_block_ready(layer)
+    n_blocks = len(sent)
+    red.finish()
+    assert sent[:n_head] == early and n_head >= 1
+    assert sent[n_head:n_blocks] == [blocks[i] for i in reversed(range(12))]
+    per_block = blocks[0][1] - blocks[0][0]
+    assert all(hi - lo == per_block for lo, hi in sent[n_head:n_blocks]) and 27e6 < per_block * 4 < 29e6
+    after = sum(hi - lo for lo, hi in sent[n_blocks:]) * 4
+    assert sent[n_blocks:] == late and after < 31e6 and after < 4e6, after          # ~3.2 MB: conv1 + embeddings + ln_pre
+    # everything that has a gradient is sent exactly once
+    total = sum(hi - lo for lo, hi in sent)
+    assert total == off - sum(pad(sizes[n]) for n in names if skip(n))
+    spans = sorted(sent)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+
+
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
@@ -223,6 +268,10 @@ mine = torch.arange(n, dtype=torch.float32) * (rank + 1)
 assert torch.equal(g[:1792], want[:1792]) and torch.equal(g[2048:], want[2048:])
 assert torch.equal(g[1792:2048], mine[1792:2048])
 assert not red.pending
+# DDP broadcast_buffers: float statistics and integer counters of rank 0 land on every rank
+bufs = [torch.full((8,), 1.0 + rank), torch.full((3, 2), 10.0 * (rank + 1)), torch.tensor(5 + rank, dtype=torch.int64)]
+red.broadcast_buffers(bufs)
+assert torch.equal(bufs[0], torch.full((8,), 1.0)) and torch.equal(bufs[1], torch.full((3, 2), 10.0)) and int(bufs[2]) == 5
 dist.destroy_process_group()
 print("ok", rank)
 '''

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from signal_amd.utils.metrics import R1_mAP_eval, eval_func
+from signal_amd.utils.metrics import R1_mAP, R1_mAP_eval, eval_func, eval_func_msrv, make_evaluator
 
 
 def test_eval_func_hand_derived_with_same_camera_filter():
@@ -27,6 +27,45 @@ def test_eval_func_hand_derived_with_same_camera_filter():
     cmc, mAP = eval_func(dist, q_pids, g_pids, q_cams, g_cams, max_rank=3)
     np.testing.assert_allclose(cmc, [0.0, 0.5, 0.5])
     assert mAP == pytest.approx(0.375)
+
+
+def test_eval_func_msrv_hand_derived_same_scene_filter():
+    """MSVR310 protocol (utils/metrics.py:13-109): same identity AND same SCENE are discarded; cameras do not enter.  Same
+    distances as the camera-protocol case above with scene ids that differ from the camera ids, so the two protocols give
+    different numbers."""
+    q_pids, q_cams, q_scn = np.array([1, 2]), np.array([0, 1]), np.array([5, 6])
+    g_pids = np.array([1, 1, 2, 3, 2, 3])
+    g_cams = np.array([0, 1, 0, 0, 1, 1])
+    g_scn = np.array([7, 5, 6, 5, 7, 6])
+    dist = np.array([[0.10, 0.50, 0.30, 0.20, 0.60, 0.40],     # q0 order: g0 g3 g2 g5 g1 g4
+                     [0.40, 0.30, 0.20, 0.10, 0.05, 0.60]])    # q1 order: g4 g3 g2 g1 g0 g5
+    # q0 (pid 1, scene 5): g1 (pid 1, scene 5) dropped; g0 (same camera but scene 7) STAYS.  kept g0 g3 g2 g5 g4 -> 1 0 0 0 0
+    #   cmc[:3] = 1 1 1 ; AP = 1
+    # q1 (pid 2, scene 6): g2 (pid 2, scene 6) dropped; g4 (same camera, scene 7) stays.  kept g4 g3 g1 g0 g5 -> 1 0 0 0 0
+    #   cmc[:3] = 1 1 1 ; AP = 1
+    cmc, mAP = eval_func_msrv(dist, q_pids, g_pids, q_cams, g_cams, q_scn, g_scn, max_rank=3)
+    np.testing.assert_allclose(cmc, [1.0, 1.0, 1.0])
+    assert mAP == pytest.approx(1.0)
+    # the camera protocol on the same data: 0.375 (case above)
+    assert eval_func(dist, q_pids, g_pids, q_cams, g_cams, max_rank=3)[1] == pytest.approx(0.375)
+    # a scene layout where the scene filter removes the ONLY early match of q0
+    g_scn2 = np.array([5, 7, 6, 5, 7, 6])
+    # q0: g0 (pid 1, scene 5) dropped; kept g3 g2 g5 g1 g4 -> 0 0 0 1 0 : cmc 0 0 0, AP 1/4.  q1 as before -> cmc 1 1 1, AP 1
+    cmc, mAP = eval_func_msrv(dist, q_pids, g_pids, q_cams, g_cams, q_scn, g_scn2, max_rank=3)
+    np.testing.assert_allclose(cmc, [0.5, 0.5, 0.5])
+    assert mAP == pytest.approx(0.625)
+
+
+def test_make_evaluator_selects_the_scene_protocol_for_msvr310():
+    from signal_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    cfg.DATASETS.NAMES = "MSVR310"
+    ev = make_evaluator(cfg, 4)
+    assert type(ev) is R1_mAP
+    ev.update((torch.zeros(2, 8), [1, 2], [0, 1], [5, 6], ["a", "b"]))
+    assert ev.sceneids == [5, 6] and ev.camids == [0, 1] and ev.img_paths == ["a", "b"]
+    cfg.DATASETS.NAMES = "RGBNT201"
+    assert type(make_evaluator(cfg, 4)) is R1_mAP_eval
 
 
 def test_eval_func_multiple_relevant_items_average_precision():
