@@ -92,6 +92,7 @@ typedef struct SigTnJobDesc {
     const uint16_t* Q;   /* X  [Mr, ldq] */
     float* out;          /* dW [I, ldo] */
     int ldp, ldq, ldo, I, J;
+    float* colsum;       /* NULL, or [I]: += column sums of P over the rows = the bias gradient that goes with dW */
 } SigTnJobDesc;
 int sig_gemm_tn_grouped(const SigTnJobDesc* jobs, int n, int Mr, int dtype, void* stream);
 

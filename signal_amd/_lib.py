@@ -55,7 +55,7 @@ class SigVitDims(C.Structure):
 
 
 class SigTnJobDesc(C.Structure):
-    _fields_ = [("P", _vp), ("Q", _vp), ("out", _vp)] + [(n, _i) for n in ("ldp", "ldq", "ldo", "I", "J")]
+    _fields_ = [("P", _vp), ("Q", _vp), ("out", _vp)] + [(n, _i) for n in ("ldp", "ldq", "ldo", "I", "J")] + [("colsum", _vp)]
 
 
 SigEmbedParams = _struct("SigEmbedParams", ["w_conv", "class_embedding", "positional_embedding", "cv_embed", "ln_w", "ln_b"],

@@ -53,6 +53,7 @@ int sig_gemm_tn_grouped(const SigTnJobDesc* jobs, int n, int Mr, int dtype, void
     for (int k = 0; k < n; ++k) {
         j[k].P = jobs[k].P; j[k].Q = jobs[k].Q; j[k].out = jobs[k].out;
         j[k].ldp = jobs[k].ldp; j[k].ldq = jobs[k].ldq; j[k].ldo = jobs[k].ldo; j[k].I = jobs[k].I; j[k].J = jobs[k].J;
+        j[k].colsum = jobs[k].colsum;
     }
     return sig_launch_gemm_tn_grouped(j, n, Mr, dtype, (hipStream_t)stream);
 }

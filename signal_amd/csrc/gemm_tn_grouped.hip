@@ -29,6 +29,7 @@ struct SigTnGroup {
     int tile0[SIG_TN_MAX_JOBS + 1];   // first tile of each job; tile0[njobs] = tiles
     int njobs, tiles, ks, grid;
     int nsplit, per;                  // row chunks and K-steps per chunk (the last chunk may be shorter)
+    int cs_job, cs_panels;            // job whose P column sums are wanted (-1: none) and its 256-column panels
     float* ws;                        // [nsplit * tiles] slots of 65536 floats, slot = chunk * tiles + tile
 };
 
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int units = p.nsplit * p.tiles;
+    const int gemm_units = p.nsplit * p.tiles;
+    const int units = gemm_units + (p.cs_job >= 0 ? p.cs_panels * p.nsplit : 0);
 
     // transposed-read addressing: lane = 16*G + 4*tq + pp addresses row (8G + tq), columns 4pp.. of a 16-column tile and
     // receives column (4tq + pp) = lane & 15, rows 8G .. 8G+3 (+4 for the second read)
@@ -73,6 +75,52 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
 
 #pragma unroll 1
     for (int unit = id; unit < units; unit += p.grid) {
+        if (unit >= gemm_units) {
+            // ---- a column-sum unit: colsum[panel * 256 ..] += sum over the chunk's rows of P[:, panel * 256 ..] (the bias
+            // gradient that goes with job cs_job's dW).  These units come after the GEMM units, i.e. they run on CUs the GEMM
+            // round leaves idle (B = 64: 216 GEMM units + 18 of these on 256 CUs) and read rows the GEMM tiles of the same
+            // chunk are streaming through L2 anyway: the 24-us column-sum pass over dY per block disappears from the stream. ----
+            const int cu = unit - gemm_units, chunk = cu / p.cs_panels, panel = cu - chunk * p.cs_panels;
+            const SigTnJob& job = p.job[p.cs_job];
+            const int r0 = chunk * p.per * 64;
+            int r1 = r0 + p.per * 64;
+            if (r1 > p.ks * 64) r1 = p.ks * 64;
+            // 512 threads = 16 rows x 32 column groups of 8; a thread owns 8 columns and every 16th row of the chunk
+            const int cg = tid & 31, rr = tid >> 5;
+            const bf16_t* src = job.P + (size_t)(panel << 8) + cg * 8;
+            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int r = r0 + rr; r < r1; r += 64) {          // 4 rows in flight per thread
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = r + 16 * k;
+                    v[k] = row < r1 ? *(const uint4*)(src + (size_t)row * job.ldp) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a8[2 * e] += cvt16f_t<DT>((bf16_t)(w[e] & 0xffff));
+                        a8[2 * e + 1] += cvt16f_t<DT>((bf16_t)(w[e] >> 16));
+                    }
+                }
+            }
+            float* red = (float*)smem;                         // [16][256]
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rr * 256 + cg * 8 + e] = a8[e];
+            __syncthreads();
+            if (tid < 256) {
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sum += red[k * 256 + tid];     // fixed order
+                // one add per row chunk lands on each address; with two chunks the float sum is order-independent
+                atomicAdd(job.colsum + (panel << 8) + tid, sum);
+            }
+            __syncthreads();
+            continue;
+        }
         const int chunk = unit / p.tiles, t = unit - chunk * p.tiles;
         const int k0 = chunk * p.per;
         const int nk = (k0 + p.per < p.ks ? k0 + p.per : p.ks) - k0;     // >= 1: the launcher makes every chunk non-empty
@@ -299,11 +347,19 @@ static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int t
         flops += 2.0 * Mr * jobs[k].I * jobs[k].J;
     }
     for (int k = njobs; k <= SIG_TN_MAX_JOBS; ++k) g.tile0[k] = t0;
+    g.cs_job = -1;
+    for (int k = 0; k < njobs; ++k)
+        if (jobs[k].colsum) {
+            SIG_CHECK_ARG(g.cs_job < 0, "gemm_tn_grouped: at most one job may ask for column sums");
+            g.cs_job = k;
+            g.cs_panels = jobs[k].I >> 8;
+        }
     g.njobs = njobs; g.tiles = tiles; g.ks = Mr >> 6;
     const int want = tng_choose_split(tiles, g.ks, grid);
     g.per = sig_ceil_div(g.ks, want);
     g.nsplit = sig_ceil_div(g.ks, g.per);
-    g.grid = g.nsplit * tiles < grid ? g.nsplit * tiles : grid;
+    const int all_units = g.nsplit * tiles + (g.cs_job >= 0 ? g.cs_panels * g.nsplit : 0);
+    g.grid = all_units < grid ? all_units : grid;
     g.ws = sig_stream_scratch(st, (size_t)g.nsplit * tiles * 65536 * sizeof(float), 0);
     SIG_CHECK_ARG(g.ws, "gemm_tn_grouped: no workspace for the partial tiles");
     const bool timed = sig_prof_tn_start(st, SIG_PROF_TN_GROUP, 0, 0);
@@ -326,9 +382,25 @@ int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, 
     SIG_CHECK_ARG(jobs && njobs >= 1 && njobs <= SIG_TN_MAX_JOBS, "gemm_tn_grouped: 1..%d jobs", SIG_TN_MAX_JOBS);
     const int grid = sig_free_cus();
     int tiles = 0;
-    if (sig_tn_grouped_enabled() && sig_tn_path() == 0 && tng_fits(jobs, njobs, Mr, &tiles))
-        return dt == SIG_DT_F16 ? launch_group<SIG_DT_F16>(jobs, njobs, Mr, grid, tiles, st)
-                                : launch_group<SIG_DT_BF16>(jobs, njobs, Mr, grid, tiles, st);
+    if (sig_tn_grouped_enabled() && sig_tn_path() == 0 && tng_fits(jobs, njobs, Mr, &tiles)) {
+        static int cs_units = -1;   // SIG_TN_CS=0: column sums as their own pass instead of units of the grouped launch (A/B runs)
+        if (cs_units < 0) { const char* e = getenv("SIG_TN_CS"); cs_units = e ? atoi(e) : 1; }
+        SigTnJob tmp[SIG_TN_MAX_JOBS];
+        const SigTnJob* use = jobs;
+        if (!cs_units) {
+            for (int k = 0; k < njobs; ++k) { tmp[k] = jobs[k]; tmp[k].colsum = nullptr; }
+            use = tmp;
+        }
+        const int rc = dt == SIG_DT_F16 ? launch_group<SIG_DT_F16>(use, njobs, Mr, grid, tiles, st)
+                                        : launch_group<SIG_DT_BF16>(use, njobs, Mr, grid, tiles, st);
+        if (rc || cs_units) return rc;
+        for (int k = 0; k < njobs; ++k)
+            if (jobs[k].colsum) {
+                const int rc2 = sig_launch_colsum_bf16(jobs[k].P, jobs[k].ldp, Mr, jobs[k].I, jobs[k].colsum, dt, st);
+                if (rc2) return rc2;
+            }
+        return 0;
+    }
     // shapes the grouped kernel does not take (outputs that are not multiples of 256): one launch per weight
     for (int k = 0; k < njobs; ++k) {
         SigGemmTN p{};
@@ -336,6 +408,10 @@ int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, 
         p.out = jobs[k].out; p.ldo = jobs[k].ldo; p.dt = dt;
         const int rc = sig_launch_gemm_tn(p, st);
         if (rc) return rc;
+        if (jobs[k].colsum) {
+            const int rc2 = sig_launch_colsum_bf16(jobs[k].P, jobs[k].ldp, Mr, jobs[k].I, jobs[k].colsum, dt, st);
+            if (rc2) return rc2;
+        }
     }
     return 0;
 }

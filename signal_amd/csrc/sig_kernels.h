@@ -63,6 +63,7 @@ struct SigTnJob {
     const bf16_t* Q;  // X  [Mr, ldq], columns J
     float* out;       // dW [I, ldo] f32, +=
     int ldp, ldq, ldo, I, J;
+    float* colsum;    // optional [I]: += column sums of P over the rows (the bias gradient that goes with dW), else nullptr
 };
 int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, hipStream_t st);
 int sig_free_cus();                                            // 256 minus the CUs reserved for RCCL (sig_tune_reserved_cus)

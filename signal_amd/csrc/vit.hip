@@ -130,21 +130,20 @@ int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
                                  g->ln2_b, M, D, dt, st, g->b_out));
     // ---- attention ----
     RUN(sig_launch_gemm_nt(nt(dt, s->dx_mid_b, D, p->wt_out, D, M, D, D, s->dh, D), SIG_EPI_BF16, st));  // d attn
-    // (in_proj bias: every (sequence) workgroup of a head would hit the same 192 addresses -- measured 2x slower with
-    //  in-kernel atomics -- so it stays a separate 25 us column-sum pass over dqkv)
+    // (in_proj bias = column sums of dqkv: by-product of the grouped weight-gradient launch below, which streams every dqkv
+    //  tile through its MFMA fragments anyway; inside the attention backward it cost 48 registers at the 256 cap)
     RUN(sig_launch_attn_bwd(a->qkv, a->attn, s->dh, a->lse, s->dqkv, d->S, d->L, d->H, dt, st));
     // ---- the block's four weight gradients: every (dY, X) pair is still in place here (dx_out_b is overwritten by the last
     // LayerNorm backward below), so they go as ONE stream-K launch + one reduce (gemm_tn_grouped.hip) ----
     {
         const SigTnJob jobs[4] = {
-            {s->dqkv, a->h1, g->w_in, 3 * D, D, D, 3 * D, D},          // attn.in_proj_weight  [3D, D]
-            {s->dx_mid_b, a->attn, g->w_out, D, D, D, D, D},           // attn.out_proj.weight [D, D]
-            {s->du, a->h2, g->w_fc, F, D, D, F, D},                    // mlp.c_fc.weight      [F, D]
-            {dx_out_b, a->g, g->w_proj, D, F, F, D, F},                // mlp.c_proj.weight    [D, F]
+            {s->dqkv, a->h1, g->w_in, 3 * D, D, D, 3 * D, D, g->b_in}, // attn.in_proj_weight [3D, D] + in_proj_bias = column sums of dqkv
+            {s->dx_mid_b, a->attn, g->w_out, D, D, D, D, D, nullptr},  // attn.out_proj.weight [D, D]
+            {s->du, a->h2, g->w_fc, F, D, D, F, D, nullptr},           // mlp.c_fc.weight      [F, D]
+            {dx_out_b, a->g, g->w_proj, D, F, F, D, F, nullptr},       // mlp.c_proj.weight    [D, F]
         };
         RUN(sig_launch_gemm_tn_grouped(jobs, 4, Mp, dt, st));
     }
-    RUN(sig_launch_colsum_bf16(s->dqkv, 3 * D, M, 3 * D, g->b_in, dt, st));
     RUN(sig_launch_gemm_nt(nt(dt, s->dqkv, 3 * D, p->wt_in, 3 * D, M, D, 3 * D, s->dh, D), SIG_EPI_BF16, st));  // dh1
     // dx_in = dx_mid + LN1'(dh1)
     RUN(sig_launch_layernorm_bwd(s->dh, 1, a->x_in, p->ln1_w, a->mean1, a->rstd1, s->dx_mid, dx_in, dx_in_b, g->ln1_w, g->ln1_b,

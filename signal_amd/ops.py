@@ -108,14 +108,16 @@ def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: torch.Tensor, split: int = 0)
 
 
 def gemm_tn_grouped(jobs) -> None:
-    """out_k += p_k.T @ q_k for up to 4 (p, q, out) triples with the same row count, as one launch (a transformer block's
-    four weight gradients)."""
+    """out_k += p_k.T @ q_k for up to 4 (p, q, out[, colsum]) jobs with the same row count, as one launch (a transformer
+    block's four weight gradients); colsum (optional, f32 [I]) += column sums of p (the bias gradient)."""
     import ctypes
     if not 1 <= len(jobs) <= 4:
         raise ValueError("gemm_tn_grouped: 1..4 jobs")
     arr = (_lib.SigTnJobDesc * len(jobs))()
     dt = rows = None
-    for k, (p, q, out) in enumerate(jobs):
+    for k, job in enumerate(jobs):
+        p, q, out = job[:3]
+        cs = job[3] if len(job) > 3 else None          # optional [I] f32: += column sums of p
         d = _chk16(p, "gemm_tn_grouped.p")
         _chk16(q, "gemm_tn_grouped.q", like=p)
         _chk(out, torch.float32, "gemm_tn_grouped.out")
@@ -125,8 +127,12 @@ def gemm_tn_grouped(jobs) -> None:
             raise ValueError("gemm_tn_grouped: the jobs must share operand type and row count")
         if tuple(out.shape) != (p.shape[1], q.shape[1]):
             raise ValueError(f"gemm_tn_grouped: out {tuple(out.shape)} vs [{p.shape[1]},{q.shape[1]}]")
+        if cs is not None:
+            _chk(cs, torch.float32, "gemm_tn_grouped.colsum", ndim=1)
+            if cs.numel() != p.shape[1]:
+                raise ValueError("gemm_tn_grouped: colsum must have one entry per column of p")
         arr[k] = _lib.SigTnJobDesc(p.data_ptr(), q.data_ptr(), out.data_ptr(), p.stride(0), q.stride(0), out.stride(0),
-                                   p.shape[1], q.shape[1])
+                                   p.shape[1], q.shape[1], _ptr(cs))
     _lib.call("sig_gemm_tn_grouped", ctypes.cast(arr, ctypes.c_void_p), len(jobs), rows, dt, _stream())
 
 

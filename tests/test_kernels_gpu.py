@@ -391,9 +391,11 @@ def test_gemm_tn_grouped_block_shapes_vs_fp64(dev, dt16, mr, reserved):
     outs = [torch.zeros(p.shape[1], q.shape[1], device=dev) for p, q in pairs]
     prev = lib.sig_tune_reserved_cus(reserved)
     try:
-        ops.gemm_tn_grouped([(p, q, o) for (p, q), o in zip(pairs, outs)])
+        bias_g = torch.zeros(3 * D, device=dev)      # in_proj bias gradient = column sums of dqkv, a by-product of job 0
+        ops.gemm_tn_grouped([(p, q, o) + ((bias_g,) if k == 0 else ()) for k, ((p, q), o) in enumerate(zip(pairs, outs))])
         for (p, q), o in zip(pairs, outs):
             assert rel_err(o, p.double().t() @ q.double()) < 5e-6, (tuple(o.shape), mr, reserved)
+        assert rel_err(bias_g, dqkv.double().sum(0)) < 5e-6
         ops.gemm_tn_grouped([(p, q, o) for (p, q), o in zip(pairs, outs)])           # += semantics
         for (p, q), o in zip(pairs, outs):
             assert rel_err(o, 2 * (p.double().t() @ q.double())) < 5e-6
@@ -417,11 +419,13 @@ def test_gemm_tn_grouped_small_batch_and_fallback(dev):
     p1, q1 = torch.randn(mr, 2304, generator=g).bfloat16().to(dev), torch.randn(mr, 768, generator=g).bfloat16().to(dev)
     p2, q2 = torch.randn(mr, 384, generator=g).bfloat16().to(dev), torch.randn(mr, 128, generator=g).bfloat16().to(dev)
     o1, o2 = torch.zeros(2304, 768, device=dev), torch.zeros(384, 128, device=dev)
-    ops.gemm_tn_grouped([(p1, q1, o1), (p2, q2, o2)])
+    c1 = torch.zeros(2304, device=dev)
+    ops.gemm_tn_grouped([(p1, q1, o1, c1), (p2, q2, o2)])
     assert rel_err(o1, p1.double().t() @ q1.double()) < 5e-6 and rel_err(o2, p2.double().t() @ q2.double()) < 5e-6
-    o3 = torch.zeros(2304, 768, device=dev)
-    ops.gemm_tn_grouped([(p1, q1, o3)])                   # multiples of 256: the grouped kernel itself
-    assert rel_err(o3, p1.double().t() @ q1.double()) < 5e-6
+    assert rel_err(c1, p1.double().sum(0)) < 5e-6          # the fallback path computes the column sums with its own pass
+    o3, c3 = torch.zeros(2304, 768, device=dev), torch.zeros(2304, device=dev)
+    ops.gemm_tn_grouped([(p1, q1, o3, c3)])               # multiples of 256: the grouped kernel itself
+    assert rel_err(o3, p1.double().t() @ q1.double()) < 5e-6 and rel_err(c3, p1.double().sum(0)) < 5e-6
     for mr2 in (64, 128, 448):                            # fewer K-steps than chunks would like
         o4 = torch.zeros(2304, 768, device=dev)
         ops.gemm_tn_grouped([(p1[:mr2], q1[:mr2], o4)])
