@@ -160,7 +160,9 @@ def committed_traffic(kernel_key, live_avg_us):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md + WRITE_SIZE; tools/profile_bench.sh).  PMC counters cannot be read from inside this process, so
     the JSON line carries the committed figure, the profile it came from and that profile's average duration; `stale` says
-    whether the kernel timed live in THIS run still is the kernel that was profiled (average duration within 10 %)."""
+    whether the kernel timed live in THIS run still is the kernel that was profiled: average duration within 30 %.  (Not 10 %:
+    the same binary of this MFMA-bound 250-320 us kernel measures 251 us on one box of the pool and 316-326 us on others, live
+    events and rocprofv3 agreeing on each box; a changed kernel moves the figure by more than that or changes its name.)"""
     for name in ("r03_traffic.json",):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
@@ -168,7 +170,7 @@ def committed_traffic(kernel_key, live_avg_us):
             ent = d.get("kernels", {}).get(kernel_key)
             if ent:
                 prof_us = ent.get("avg_us_rocprofv3")
-                stale = bool(prof_us and live_avg_us and abs(live_avg_us / prof_us - 1) > 0.10)
+                stale = bool(prof_us and live_avg_us and abs(live_avg_us / prof_us - 1) > 0.30)
                 return {"traffic": ent.get("bytes_per_launch"), "traffic_algorithmic": ent.get("algorithmic_bytes_per_launch"),
                         "traffic_source": f"profiles/{name} <- {d.get('profile_tag')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                         "traffic_profile_avg_us": prof_us, "traffic_stale": stale}

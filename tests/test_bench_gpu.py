@@ -39,7 +39,7 @@ def test_bench_default_is_the_train_step_with_the_json_contract():
     want = 2.0 * 24832 * (2304 * 768 + 768 * 768 + 2 * 3072 * 768) / (r["avg_us"] * 1e-6) / 1e12
     assert abs(r["achieved"] / want - 1) < 0.01
     # the PMC traffic figure must come from a profile of THIS kernel: bench.py flags a committed figure whose profiled average
-    # duration is more than 10 % away from the live one
+    # duration is more than 30 % away from the live one (box-to-box spread of this kernel is 251-326 us)
     assert r["traffic"] is None or (r["traffic"] > 1e8 and r["traffic_stale"] is False), r
     # the operand type that meets the north_star's 1e-3 has a driver-visible train figure of its own
     h = d["fp16"]
