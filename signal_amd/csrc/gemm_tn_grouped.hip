@@ -28,8 +28,12 @@ struct SigTnGroup {
     SigTnJob job[SIG_TN_MAX_JOBS];
     int tile0[SIG_TN_MAX_JOBS + 1];   // first tile of each job; tile0[njobs] = tiles
     int njobs, tiles, ks, grid;
-    int nsplit, per;                  // row chunks and K-steps per chunk (the last chunk may be shorter)
-    int cs_job, cs_panels;            // job whose P column sums are wanted (-1: none) and its 256-column panels
+    int nsplit, per;                  // row chunks and K-steps per chunk (the last chunk is the rest: shorter, or the "short" one)
+    int cs_job, cs_units;             // job whose P column sums are wanted (-1: none) and its 64-column slices (I / 64)
+    // balanced = 1: the first nsplit - 1 chunks are `per` K-steps long, one (chunk, tile) unit per workgroup; the LAST chunk is
+    // short (ks - (nsplit - 1) * per, about per / short_group) and a workgroup takes short_group tiles of it in turn; the
+    // column-sum units go to the workgroups after those.  balanced = 0: unit u -> workgroup u % grid (rounds).
+    int balanced, short_group, n_long, n_short_wg;
     float* ws;                        // [nsplit * tiles] slots of 65536 floats, slot = chunk * tiles + tile
 };
 
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int gemm_units = p.nsplit * p.tiles;
-    const int units = gemm_units + (p.cs_job >= 0 ? p.cs_panels * p.nsplit : 0);
+    const int units = gemm_units + (p.cs_job >= 0 ? p.cs_units : 0);
 
     // transposed-read addressing: lane = 16*G + 4*tq + pp addresses row (8G + tq), columns 4pp.. of a 16-column tile and
     // receives column (4tq + pp) = lane & 15, rows 8G .. 8G+3 (+4 for the second read)
@@ -74,30 +78,41 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
     using F_ = std::integral_constant<bool, false>;
 
 #pragma unroll 1
-    for (int unit = id; unit < units; unit += p.grid) {
+    for (int it = 0;; ++it) {
+        // ---- this workgroup's it-th unit ----
+        int unit;
+        if (!p.balanced) {
+            unit = id + it * p.grid;
+        } else if (id < p.n_long) {
+            unit = it == 0 ? id : units;
+        } else if (id < p.n_long + p.n_short_wg) {
+            const int tile = (id - p.n_long) * p.short_group + it;
+            unit = (it < p.short_group && tile < p.tiles) ? p.n_long + tile : units;
+        } else {
+            unit = gemm_units + (id - p.n_long - p.n_short_wg) + it * (p.grid - p.n_long - p.n_short_wg);
+        }
+        if (unit >= units) break;
         if (unit >= gemm_units) {
-            // ---- a column-sum unit: colsum[panel * 256 ..] += sum over the chunk's rows of P[:, panel * 256 ..] (the bias
-            // gradient that goes with job cs_job's dW).  These units come after the GEMM units, i.e. they run on CUs the GEMM
-            // round leaves idle (B = 64: 216 GEMM units + 18 of these on 256 CUs) and read rows the GEMM tiles of the same
-            // chunk are streaming through L2 anyway: the 24-us column-sum pass over dY per block disappears from the stream. ----
-            const int cu = unit - gemm_units, chunk = cu / p.cs_panels, panel = cu - chunk * p.cs_panels;
+            // ---- a column-sum unit: colsum[c0 .. c0 + 64) += sum over ALL rows of P[:, c0 .. c0 + 64) (the bias gradient that
+            // goes with job cs_job's dW).  These units run on the CUs the GEMM units leave idle and read rows that GEMM tiles
+            // are streaming through L2 / the Infinity Cache anyway: the 24-us column-sum pass over dY per block disappears from
+            // the stream.  One writer per address, fixed summation order: deterministic. ----
             const SigTnJob& job = p.job[p.cs_job];
-            const int r0 = chunk * p.per * 64;
-            int r1 = r0 + p.per * 64;
-            if (r1 > p.ks * 64) r1 = p.ks * 64;
-            // 512 threads = 16 rows x 32 column groups of 8; a thread owns 8 columns and every 16th row of the chunk
-            const int cg = tid & 31, rr = tid >> 5;
-            const bf16_t* src = job.P + (size_t)(panel << 8) + cg * 8;
+            const int c0 = (unit - gemm_units) * 64;
+            // 512 threads = 64 rows x 8 column groups of 8; a thread owns 8 columns and every 64th row
+            const int cg = tid & 7, rr = tid >> 3;
+            const bf16_t* src = job.P + c0 + cg * 8;
+            const int rows = p.ks * 64;
             float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int r = r0 + rr; r < r1; r += 64) {          // 4 rows in flight per thread
-                uint4 v[4];
+            for (int r = rr; r < rows; r += 512) {             // 8 rows (128 KB per CU) in flight: ~60 GB/s per CU at HBM latency
+                uint4 v[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = r + 16 * k;
-                    v[k] = row < r1 ? *(const uint4*)(src + (size_t)row * job.ldp) : make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < 8; ++k) {
+                    const int row = r + 64 * k;
+                    v[k] = row < rows ? *(const uint4*)(src + (size_t)row * job.ldp) : make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 8; ++k) {
                     const unsigned w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -106,24 +121,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
                     }
                 }
             }
-            float* red = (float*)smem;                         // [16][256]
+            float* red = (float*)smem;                         // [64][64]
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[rr * 256 + cg * 8 + e] = a8[e];
+            for (int e = 0; e < 8; ++e) red[rr * 64 + cg * 8 + e] = a8[e];
             __syncthreads();
-            if (tid < 256) {
+            if (tid < 64) {
                 float sum = 0.f;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) sum += red[k * 256 + tid];     // fixed order
-                // one add per row chunk lands on each address; with two chunks the float sum is order-independent
-                atomicAdd(job.colsum + (panel << 8) + tid, sum);
+#pragma unroll 16
+                for (int k = 0; k < 64; ++k) sum += red[k * 64 + tid];      // fixed order
+                job.colsum[c0 + tid] += sum;
             }
             __syncthreads();
             continue;
         }
         const int chunk = unit / p.tiles, t = unit - chunk * p.tiles;
         const int k0 = chunk * p.per;
-        const int nk = (k0 + p.per < p.ks ? k0 + p.per : p.ks) - k0;     // >= 1: the launcher makes every chunk non-empty
+        const int nk = (chunk + 1 < p.nsplit ? k0 + p.per : p.ks) - k0;   // >= 1: the launcher makes every chunk non-empty
         int jb = 0;
 #pragma unroll
         for (int q = 1; q < SIG_TN_MAX_JOBS; ++q)
@@ -329,6 +343,61 @@ static int tng_choose_split(int tiles, int ks, int grid) {
     return best;
 }
 
+// Work plan.  Uniform: nsplit equal chunks, units in rounds of the grid (tng_choose_split).  Balanced (when it fits the free
+// CUs and pays): with `tiles` < CUs < 3 x tiles no uniform split fills the chip -- B = 64: 108 tiles x 2 chunks = 216 of 256 CUs
+// for 194 K-steps.  So nl "long" chunks of `per` K-steps take one workgroup per (chunk, tile), the rest of the rows is one SHORT
+// chunk of about per / sg K-steps, and a workgroup takes sg tiles of it in turn: nl * tiles + ceil(tiles / sg) workgroups that all
+// work ~per K-steps.  B = 64: 2 x 108 long units of 176 K-steps + 27 workgroups x 4 short units of 36 = 243 CUs busy for ~180
+// K-steps instead of 216 for 202, the 13 CUs left take the 36 column-sum units.
+static void tng_plan(SigTnGroup& g, int grid, int cs_units) {
+    static int allow = -1;      // SIG_TN_BALANCED=0: uniform chunks only (A/B runs)
+    if (allow < 0) { const char* e = getenv("SIG_TN_BALANCED"); allow = e ? atoi(e) : 1; }
+    const int tiles = g.tiles, ks = g.ks;
+    const int want = tng_choose_split(tiles, ks, grid);
+    int per = sig_ceil_div(ks, want);
+    const int nsplit = sig_ceil_div(ks, per);
+    // uniform: the GEMM units in rounds; column-sum units that do not fit the last round's idle CUs add their own short tail
+    const long long uni_rounds = sig_ceil_div(nsplit * tiles, grid);
+    const int idle = (int)(uni_rounds * grid) - nsplit * tiles;
+    long long best_cost = uni_rounds * (per + 8) + (long long)(0.04 * nsplit * tiles) +
+                          (cs_units > idle ? (long long)sig_ceil_div(cs_units - idle, grid) * (ks / 8 + 4) : 0);
+    g.balanced = 0; g.nsplit = nsplit; g.per = per; g.short_group = 0; g.n_long = 0; g.n_short_wg = 0;
+    const int all_units = nsplit * tiles + cs_units;
+    g.grid = all_units < grid ? all_units : grid;
+    if (!allow) return;
+    static int f_nl = -1, f_sg = 0, f_pl = 0;   // SIG_TN_PLAN="nl,sg[,per_long]": pin the balanced plan (A/B runs)
+    if (f_nl < 0) {
+        f_nl = 0;
+        const char* e = getenv("SIG_TN_PLAN");
+        if (e) sscanf(e, "%d,%d,%d", &f_nl, &f_sg, &f_pl);
+    }
+    for (int nl = 1; nl <= 4; ++nl)
+        for (int sg = 2; sg <= 6; ++sg) {
+            if (f_nl > 0 && (nl != f_nl || sg != f_sg)) continue;
+            const int wgs = nl * tiles + sig_ceil_div(tiles, sg);
+            const int cs_wg = cs_units ? (grid - wgs) : 0;
+            if (wgs > grid || (cs_units && cs_wg < 1)) continue;
+            // long units: per + 8; short workgroups: sg * (ps + 8); balance them
+            int pl = sig_ceil_div(sg * ks + 8 * sg - 8, nl * sg + 1);
+            if (f_nl > 0 && f_pl > 0) pl = f_pl;
+            if (pl * nl >= ks) continue;
+            const int ps = ks - pl * nl;
+            if (ps < 4) continue;
+            const long long t_long = pl + 8, t_short = (long long)sg * (ps + 8);
+            // a column-sum unit streams ks * 64 rows x 128 B at ~50 GB/s: about ks / 8 K-step times
+            const long long t_cs = cs_units ? (long long)sig_ceil_div(cs_units, cs_wg) * (ks / 8 + 4) : 0;
+            long long cost = t_long > t_short ? t_long : t_short;
+            if (t_cs > cost) cost = t_cs;
+            cost += (long long)(0.04 * (nl + 1) * tiles);
+            if (cost < best_cost || f_nl > 0) {
+                best_cost = cost;
+                g.balanced = 1; g.nsplit = nl + 1; g.per = pl; g.short_group = sg; g.n_long = nl * tiles;
+                g.n_short_wg = sig_ceil_div(tiles, sg);
+                g.grid = cs_units ? grid : wgs;
+            }
+        }
+}
+
 template <int DT>
 static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int tiles, hipStream_t st) {
     static bool attr_done = false;
@@ -352,14 +421,11 @@ static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int t
         if (jobs[k].colsum) {
             SIG_CHECK_ARG(g.cs_job < 0, "gemm_tn_grouped: at most one job may ask for column sums");
             g.cs_job = k;
-            g.cs_panels = jobs[k].I >> 8;
         }
     g.njobs = njobs; g.tiles = tiles; g.ks = Mr >> 6;
-    const int want = tng_choose_split(tiles, g.ks, grid);
-    g.per = sig_ceil_div(g.ks, want);
-    g.nsplit = sig_ceil_div(g.ks, g.per);
-    const int all_units = g.nsplit * tiles + (g.cs_job >= 0 ? g.cs_panels * g.nsplit : 0);
-    g.grid = all_units < grid ? all_units : grid;
+    const int cs_units = g.cs_job >= 0 ? jobs[g.cs_job].I >> 6 : 0;
+    g.cs_units = cs_units;
+    tng_plan(g, grid, cs_units);
     g.ws = sig_stream_scratch(st, (size_t)g.nsplit * tiles * 65536 * sizeof(float), 0);
     SIG_CHECK_ARG(g.ws, "gemm_tn_grouped: no workspace for the partial tiles");
     const bool timed = sig_prof_tn_start(st, SIG_PROF_TN_GROUP, 0, 0);
