@@ -440,9 +440,12 @@ class HipPath:
 
     def shared_dtokens(self, tokens: torch.Tensor):
         lt = self._live_tokens
-        if lt is not None and lt[0] == tokens.data_ptr() and tuple(tokens.shape) == lt[1]:
-            return lt[2]
-        return None
+        if lt is None or lt[0] != tokens.data_ptr() or tuple(tokens.shape) != lt[1]:
+            return None
+        # the SAME tensor (or a full view of it), not merely a tensor that happens to start at the same address
+        base = tokens._base if tokens._base is not None else tokens
+        live = lt[3]._base if lt[3]._base is not None else lt[3]
+        return lt[2] if base is live or tokens is lt[3] else None
 
     # ------------------------------------------------------------------ SIM
     def _alloc_sim(self, B, train):
@@ -548,8 +551,15 @@ class BackboneFn(torch.autograd.Function):
             out = view.clone()                       # the inference workspace goes back to the pool right away
             ctx.lease.release()
             return out, cls
-        # training: the workspace is held until backward, so the tokens are handed out in place (no 50 MB clone)
-        hip._live_tokens = (view.data_ptr(), tuple(view.shape), ws["dtokens"][:M].view(ws["S"], hip.L, hip.out_dim))
+        import os
+        if os.environ.get("SIGNAL_CLONE_TOKENS") == "1":
+            # debug aid ("Lifetime of the token tensor"): a private copy that outlives the workspace; the heads'
+            # backward stages then return their gradients through autograd instead of accumulating in place
+            hip._live_tokens = None
+            return view.clone(), cls
+        # training: the workspace is held until backward, so the tokens are handed out in place (no 50 MB clone); valid until
+        # that backward or the next training forward
+        hip._live_tokens = (view.data_ptr(), tuple(view.shape), ws["dtokens"][:M].view(ws["S"], hip.L, hip.out_dim), view)
         return view, cls
 
     @staticmethod
