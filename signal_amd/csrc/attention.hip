@@ -464,6 +464,10 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
 #ifdef SIG_ATTN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ATT_STAMP(ta3);
+#ifdef SIG_ATTN_HWID   // tools/attn_timeline.py: where the block ran instead of the pass-A stamp (HW_ID = reg 4, XCC_ID = reg 20)
+    ta2 = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32) |
+          (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+#endif
     if (tid == 0 && blockIdx.x < 4096) {
         g_astamps[blockIdx.x * 4 + 0] = ta0; g_astamps[blockIdx.x * 4 + 1] = ta1;
         g_astamps[blockIdx.x * 4 + 2] = ta2; g_astamps[blockIdx.x * 4 + 3] = ta3;
