@@ -86,7 +86,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
         } else if (id < p.n_long) {
             unit = it == 0 ? id : units;
         } else if (id < p.n_long + p.n_short_wg) {
-            const int tile = (id - p.n_long) * p.short_group + it;
+            // the short workgroups' it-th units are n_short_wg CONSECUTIVE tiles: neighbours share dY / X panels in L2
+            const int tile = it * p.n_short_wg + (id - p.n_long);
             unit = (it < p.short_group && tile < p.tiles) ? p.n_long + tile : units;
         } else {
             unit = gemm_units + (id - p.n_long - p.n_short_wg) + it * (p.grid - p.n_long - p.n_short_wg);
