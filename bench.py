@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-sim", action="store_true", help="skip the forward-only sub-measurement")
     ap.add_argument("--no-other-dtype", action="store_true", help="skip the train-step sub-measurement with the other operand type")
+    ap.add_argument("--ddp-single", action="store_true", help="N = 1 only: create a ONE-rank RCCL (nccl) process group and drive the whole "
+                    "data-parallel exchange path (bucket plan, backward hooks, asynchronous all-reduces on RCCL's stream, reserved-CU sizing) "
+                    "on this GPU; the sum over one rank is the identity.  Reported in `ddp_single`, never the headline")
     ap.add_argument("--h2d", action="store_true", help="also report the rate with batches coming from pinned host memory "
                     "through signal_amd.data.DevicePrefetcher (PCIe-inclusive; never the headline value)")
     return ap.parse_args()
@@ -304,6 +307,24 @@ def main():
             other["loss_scale"] = ots.scaler.describe()
         del ots, omodel
 
+    ddp_single = None
+    if args.ddp_single and world == 1 and args.workload == "train":
+        import torch.distributed as tdist
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("SIGNAL_RESERVED_CUS", "16"))
+        tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        dcfg, dmodel = build_model(dev, args.dtype, args.config)
+        dts = TrainStep(dcfg, dmodel, num_classes=ncls, world_size=1, force_reducer=True)
+        del_, (dms, dn, dfl) = timed(lambda: dts.step(img, vid, cam), args.steps, args.warmup, prof)
+        ddp_single = {"value": round(B * args.steps / del_, 2), "unit": "triplets/s", "ms_per_step": round(del_ / args.steps * 1e3, 3),
+                      "reserved_cus": dts.reserved_cus, "buckets_per_step": len(dts.reducer.blocks) + len(dts.reducer.rest) + len(dts.reducer.rest_early),
+                      "note": "one-rank RCCL group on this GPU: every gradient bucket goes through ncclAllReduce on RCCL's stream under the "
+                              "backward (sum over one rank = identity), backward GEMMs sized for 256 - reserved_cus CUs"}
+        tdist.destroy_process_group()
+        del dts, dmodel
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -326,6 +347,8 @@ def main():
     }
     if other is not None:
         out[other["dtype"]] = other
+    if ddp_single is not None:
+        out["ddp_single"] = ddp_single
     if loss_scale_desc is not None:
         out["config"]["loss_scale"] = loss_scale_desc
     if fwd is not None:

@@ -350,7 +350,21 @@ static int tng_choose_split(int tiles, int ks, int grid) {
 // chunk of about per / sg K-steps, and a workgroup takes sg tiles of it in turn: nl * tiles + ceil(tiles / sg) workgroups that all
 // work ~per K-steps.  B = 64: 2 x 108 long units of 176 K-steps + 27 workgroups x 4 short units of 36 = 243 CUs busy for ~180
 // K-steps instead of 216 for 202, the 13 CUs left take the 36 column-sum units.
-static void tng_plan(SigTnGroup& g, int grid, int cs_units) {
+static void tng_plan_one(SigTnGroup& g, int grid, int cs_units, long long* cost_out);
+// -> true when the column sums should run as units of this launch, false when a separate pass after it is cheaper (e.g. with
+// CUs reserved for RCCL the balanced plan leaves no CU for them: 240 CUs = 216 long + 22 short workgroups)
+static bool tng_plan(SigTnGroup& g, int grid, int cs_units) {
+    if (!cs_units) { long long c; tng_plan_one(g, grid, 0, &c); return false; }
+    SigTnGroup a = g, b = g;
+    long long ca = 0, cb = 0;
+    tng_plan_one(a, grid, cs_units, &ca);
+    tng_plan_one(b, grid, 0, &cb);
+    cb += 17;                               // the separate column-sum pass: ~24 us ~ 17 K-step times
+    if (ca <= cb) { g = a; return true; }
+    g = b;
+    return false;
+}
+static void tng_plan_one(SigTnGroup& g, int grid, int cs_units, long long* cost_out) {
     static int allow = -1;      // SIG_TN_BALANCED=0: uniform chunks only (A/B runs)
     if (allow < 0) { const char* e = getenv("SIG_TN_BALANCED"); allow = e ? atoi(e) : 1; }
     const int tiles = g.tiles, ks = g.ks;
@@ -365,6 +379,7 @@ static void tng_plan(SigTnGroup& g, int grid, int cs_units) {
     g.balanced = 0; g.nsplit = nsplit; g.per = per; g.short_group = 0; g.n_long = 0; g.n_short_wg = 0;
     const int all_units = nsplit * tiles + cs_units;
     g.grid = all_units < grid ? all_units : grid;
+    *cost_out = best_cost;
     if (!allow) return;
     static int f_nl = -1, f_sg = 0, f_pl = 0;   // SIG_TN_PLAN="nl,sg[,per_long]": pin the balanced plan (A/B runs)
     if (f_nl < 0) {
@@ -395,6 +410,7 @@ static void tng_plan(SigTnGroup& g, int grid, int cs_units) {
                 g.balanced = 1; g.nsplit = nl + 1; g.per = pl; g.short_group = sg; g.n_long = nl * tiles;
                 g.n_short_wg = sig_ceil_div(tiles, sg);
                 g.grid = cs_units ? grid : wgs;
+                *cost_out = best_cost;
             }
         }
 }
@@ -424,9 +440,10 @@ static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int t
             g.cs_job = k;
         }
     g.njobs = njobs; g.tiles = tiles; g.ks = Mr >> 6;
-    const int cs_units = g.cs_job >= 0 ? jobs[g.cs_job].I >> 6 : 0;
+    int cs_units = g.cs_job >= 0 ? jobs[g.cs_job].I >> 6 : 0;
+    const int cs_job = g.cs_job;
+    if (!tng_plan(g, grid, cs_units)) { cs_units = 0; g.cs_job = -1; }
     g.cs_units = cs_units;
-    tng_plan(g, grid, cs_units);
     g.ws = sig_stream_scratch(st, (size_t)g.nsplit * tiles * 65536 * sizeof(float), 0);
     SIG_CHECK_ARG(g.ws, "gemm_tn_grouped: no workspace for the partial tiles");
     const bool timed = sig_prof_tn_start(st, SIG_PROF_TN_GROUP, 0, 0);
@@ -435,6 +452,8 @@ static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int t
     SIG_CHECK_LAUNCH("gemm_tn_group");
     hipLaunchKernelGGL(tn_group_reduce_kernel, dim3(tiles * 64), dim3(256), 0, st, g);
     SIG_CHECK_LAUNCH("tn_group_reduce");
+    if (cs_job >= 0 && g.cs_job < 0)       // the plan left the column sums out of the launch: their own pass
+        return sig_launch_colsum_bf16(jobs[cs_job].P, jobs[cs_job].ldp, Mr, jobs[cs_job].I, jobs[cs_job].colsum, DT, st);
     return 0;
 }
 

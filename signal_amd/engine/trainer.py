@@ -50,7 +50,10 @@ class DeviceLossScaler:
 
 
 class TrainStep:
-    def __init__(self, cfg, model, num_classes, world_size=1, loss_fn=None, optimizer=None, stage=None):
+    def __init__(self, cfg, model, num_classes, world_size=1, loss_fn=None, optimizer=None, stage=None, force_reducer=False):
+        """force_reducer: build and drive the data-parallel reducer even with world_size 1 (needs an initialised process group):
+        a single GPU then executes the complete exchange path -- bucket plan, hooks, asynchronous RCCL all-reduces on their side
+        stream under the backward, the reserved-CU sizing of an nccl group -- with the identity as the sum (tests, bench --ddp-single)."""
         self.cfg, self.model = cfg, model
         # the raw string, as the reference compares it (its default 'CLS ' -- with the space -- takes the GAM+LAM branch)
         self.stage = cfg.MODEL.stageName if stage is None else stage
@@ -84,7 +87,8 @@ class TrainStep:
         # +0.3 % (measured); not reserving costs a second round on every 234-tile GEMM that meets a bucket in flight.
         # UNMEASURED against real RCCL traffic (no multi-GPU box this round or the last).
         self.reserved_cus = 0
-        if world_size > 1 and torch.distributed.is_initialized():
+        ddp = (world_size > 1 or force_reducer) and torch.distributed.is_initialized()
+        if ddp:
             env = os.environ.get("SIGNAL_RESERVED_CUS")
             if env is not None:
                 self.reserved_cus = int(env)
@@ -92,12 +96,12 @@ class TrainStep:
                 self.reserved_cus = 16
         if self.reserved_cus and not hasattr(_lib.load(), "sig_tune_reserved_cus"):
             self.reserved_cus = 0          # an older library without the tuning exports (_lib._TUNING_ONLY): nothing to size
-        if world_size > 1:
+        if ddp:
             fl = hip.flat
             sizes = {n: fl.byname[n].numel() for n in fl.names}
             blocks, _ = plan_buckets(fl.names, fl.offsets, sizes, fl.total, skip=self.inactive)
             early, late = split_rest(fl.names, fl.offsets, sizes, skip=self.inactive, late_names=hip.embed_param_names)
-            self.reducer = GradReducer(fl.grad, blocks, late, rest_early=early)
+            self.reducer = GradReducer(fl.grad, blocks, late, rest_early=early, force=force_reducer)
             self.reducer.broadcast_params(fl.data)      # DDP's construction-time broadcast from rank 0 (parameters ...
             self._buffers = [b for _, b in model.named_buffers()]
             self.reducer.broadcast_buffers(self._buffers)   # ... and buffers)

@@ -70,20 +70,23 @@ def plan_buckets(names: Sequence[str], offsets: Dict[str, int], sizes: Dict[str,
 
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, block_buckets: Dict[int, Tuple[int, int]], rest: List[Tuple[int, int]],
-                 group=None, rest_early: List[Tuple[int, int]] = None):
-        """rest = ranges reduced by finish(); rest_early (optional) = ranges reduced by on_head_ready()."""
+                 group=None, rest_early: List[Tuple[int, int]] = None, force: bool = False):
+        """rest = ranges reduced by finish(); rest_early (optional) = ranges reduced by on_head_ready().
+        force: issue the collectives even in a one-rank group (the sum over one rank is the identity) -- lets a single GPU
+        execute the whole exchange path (RCCL kernels on their side stream under the backward) for tests and measurements."""
         self.g, self.blocks, self.rest, self.group = flat_grad, block_buckets, rest, group
         self.rest_early = rest_early or []
         self._early_done = False
         self.pending = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
 
     def _reduce(self, lo, hi):
         self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def on_head_ready(self):
         """Call right after the head stage of the ViT backward was enqueued: every head-side gradient is final."""
-        if self.world == 1 or self._early_done:
+        if not self.active or self._early_done:
             return
         for lo, hi in self.rest_early:
             self._reduce(lo, hi)
@@ -91,14 +94,14 @@ class GradReducer:
 
     def on_block_ready(self, layer: int):
         """Call right after block `layer`'s backward was enqueued on the current stream."""
-        if self.world == 1 or layer not in self.blocks:
+        if not self.active or layer not in self.blocks:
             return
         lo, hi = self.blocks[layer]
         self._reduce(lo, hi)
 
     def finish(self):
         """Reduce the remainder and make the current stream wait for every outstanding bucket."""
-        if self.world == 1:
+        if not self.active:
             return
         self.on_head_ready()                 # (a backward that never reached the head hook, e.g. no backbone gradient)
         for lo, hi in self.rest:
@@ -110,7 +113,7 @@ class GradReducer:
 
     def broadcast_params(self, flat_data: torch.Tensor, src: int = 0):
         """Initial parameter sync (DDP construction broadcast)."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat_data, src=src, group=self.group)
 
     def broadcast_buffers(self, buffers: Sequence[torch.Tensor], src: int = 0):

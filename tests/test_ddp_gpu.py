@@ -152,3 +152,65 @@ def test_sig_comm_exports_run_over_rccl_with_one_rank():
         assert float(g[1 << 21:].abs().max()) == 0.0
     finally:
         _lib.call("sig_comm_destroy", comm)
+
+
+_ONE_RANK = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from oracle import signal_ref as O
+from tests.test_model_gpu import build
+from signal_amd.engine.trainer import TrainStep
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+ocfg = O.rgbnt201_config(num_instance=2)
+img, vid, cam = O.synthetic_batch(ocfg, 4, seed=500)
+batch = ({k: v.to(dev) for k, v in img.items()}, vid.to(dev), cam.to(dev))
+def run(force):
+    sd = O.init_state_dict(ocfg, seed=100, head_scale=30.0)
+    model = build(ocfg, sd, dev)
+    cfg = model.cfg
+    cfg.SOLVER.OPTIMIZER_NAME = "Adam"; cfg.SOLVER.BASE_LR = 3.5e-4
+    ts = TrainStep(cfg, model, num_classes=ocfg.num_classes, world_size=1, force_reducer=force)
+    sent = []
+    if force:
+        assert ts.reducer is not None and ts.reducer.active and ts.reserved_cus == 16, (ts.reducer, ts.reserved_cus)
+        orig = ts.reducer._reduce
+        ts.reducer._reduce = lambda lo, hi: (sent.append((lo, hi)), orig(lo, hi))[1]
+    for _ in range(2):
+        loss = ts.step(*batch)
+    torch.cuda.synchronize()
+    return float(loss), model.hip.flat.grad.clone(), model.hip.flat.data.clone(), sent, ts
+l0, g0, p0, _, _ = run(False)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1, device_id=dev)
+l1, g1, p1, sent, ts = run(True)
+# 2 steps x (head-side remainder + 12 block buckets + embedding group), every range through ncclAllReduce
+per_step = len(ts.reducer.rest_early) + 12 + len(ts.reducer.rest)
+assert len(sent) == 2 * per_step, (len(sent), per_step)
+blocks = [r for r in sent[:per_step] if r in ts.reducer.blocks.values()]
+assert blocks == [ts.reducer.blocks[i] for i in reversed(range(12))]
+# sum over one rank = identity; the backward ran with the tiles / grids sized for 240 CUs (another summation order only)
+err_g = float((g1 - g0).norm() / g0.norm()); err_p = float((p1 - p0).norm() / p0.norm())
+assert abs(l1 - l0) < 1e-5 * abs(l0) and err_g < 5e-6 and err_p < 1e-6, (l0, l1, err_g, err_p)
+dist.destroy_process_group()
+print("ok one-rank RCCL", len(sent), err_g)
+'''
+
+
+def test_one_rank_rccl_group_runs_the_whole_exchange_path(tmp_path):
+    """The RCCL path itself on the one GPU there is: an `nccl` process group with ONE rank, TrainStep(force_reducer=True).  Every
+    bucket of two train steps goes through torch.distributed's asynchronous ncclAllReduce on RCCL's stream, issued from the
+    backward hooks in reverse block order, waited for before the fused Adam; the nccl default of 16 reserved CUs sizes the
+    backward GEMMs.  The sum over one rank is the identity, so losses, gradients and updated parameters must equal the plain
+    single-GPU step's.  (More ranks: no multi-GPU box; unmeasured.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    script = tmp_path / "one_rank.py"
+    script.write_text(_ONE_RANK)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("SIGNAL_RESERVED_CUS", None)
+    p = subprocess.run([sys.executable, str(script), ROOT, port], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok one-rank RCCL" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
