@@ -47,6 +47,10 @@ int sig_tune_gemm_tile(int tile);
 /* Same for the weight-gradient path: 128 = the 128x128-tile kernel with f32 atomics, one launch per weight; 256 = the 256x256
  * kernel, one launch per weight; 0 = default (a block's four weights grouped into one launch).  Environment: SIG_GEMM_TN_TILE. */
 int sig_tune_tn_path(int path);
+/* Host-logic probe (no GPU needed): the grouped weight-gradient launch's work plan for `tiles` 256x256 output tiles, `ks` K-steps of
+ * 64 rows, `grid` free CUs and `cs_units` column-sum units.  out8 = {balanced, nsplit, per, short_group, n_long, n_short_wg,
+ * workgroups, column sums inside the launch (1) or as their own pass (0)}; see gemm_tn_grouped.hip (tng_plan). */
+int sig_debug_tn_plan(int tiles, int ks, int grid, int cs_units, int* out8);
 /* CUs (0..192) the GEMM launchers leave to concurrent work -- the RCCL channel workgroups that all-reduce gradient buckets
  * under the backward pass (engine/processor.py:212-261 runs DDP's reducer there).  The one-block-per-CU kernels are sized
  * in rounds of the FREE CUs; returns the previous setting.  Environment preset: SIG_RESERVED_CUS. */

@@ -29,6 +29,7 @@ int sig_prof_begin(int epilogue, int N, int K, int max_launches) { return sig_pr
 int sig_tune_gemm_tile(int tile) { return sig_tune_gemm_tile_impl(tile); }
 int sig_tune_reserved_cus(int n) { return sig_tune_reserved_cus_impl(n); }
 int sig_tune_tn_path(int path) { return sig_tune_tn_path_impl(path); }
+int sig_debug_tn_plan(int tiles, int ks, int grid, int cs_units, int* out8) { return sig_debug_tn_plan_impl(tiles, ks, grid, cs_units, out8); }
 int sig_prof_end(double* total_ms, int* launches, double* flops) { return sig_prof_end_impl(total_ms, launches, flops); }
 
 int sig_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, int epilogue, void* out,

@@ -457,6 +457,19 @@ static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int t
     return 0;
 }
 
+// Host-logic probe (tests/test_host_cpu.py, no GPU needed): the work plan for `tiles` output tiles, `ks` K-steps, `grid` free CUs
+// and `cs_units` column-sum units.  out = {balanced, nsplit, per, short_group, n_long, n_short_wg, grid, cs_inside}
+int sig_debug_tn_plan_impl(int tiles, int ks, int grid, int cs_units, int* out) {
+    SIG_CHECK_ARG(tiles > 0 && ks > 0 && grid > 0 && cs_units >= 0 && out, "debug_tn_plan: bad arguments");
+    SigTnGroup g;
+    memset(&g, 0, sizeof(g));
+    g.tiles = tiles; g.ks = ks;
+    const bool inside = tng_plan(g, grid, cs_units);
+    out[0] = g.balanced; out[1] = g.nsplit; out[2] = g.per; out[3] = g.short_group; out[4] = g.n_long; out[5] = g.n_short_wg;
+    out[6] = g.grid; out[7] = inside ? 1 : 0;
+    return 0;
+}
+
 int sig_tn_grouped_enabled() {
     static int on = -1;       // SIG_TN_GROUPED=0: the round-2 form (one launch per weight, uniform row split) for A/B runs
     if (on < 0) { const char* e = getenv("SIG_TN_GROUPED"); on = e ? atoi(e) : 1; }

@@ -66,6 +66,7 @@ struct SigTnJob {
     float* colsum;    // optional [I]: += column sums of P over the rows (the bias gradient that goes with dW), else nullptr
 };
 int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, hipStream_t st);
+int sig_debug_tn_plan_impl(int tiles, int ks, int grid, int cs_units, int* out);
 int sig_free_cus();                                            // 256 minus the CUs reserved for RCCL (sig_tune_reserved_cus)
 #ifndef SIG_PROF_TN_GROUP
 #define SIG_PROF_TN_GROUP 101   // sig_prof_begin class: gemm_tn_group_kernel launches (a block's four weight gradients)

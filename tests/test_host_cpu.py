@@ -224,7 +224,7 @@ def test_backward_hook_order_issues_buckets_in_reverse_block_order():
     early, late = split_rest(names, offsets, sizes, skip=skip, late_names=embed)
     assert (early, late) == split_rest(names, offsets, sizes, skip=skip)     # the engine's list and the name rule agree today
     red = GradReducer(torch.zeros(1), blocks, late, rest_early=early)
-    red.world = 2                                   # pretend: record instead of communicating
+    red.world, red.active = 2, True                 # pretend: record instead of communicating
     sent = []
     red._reduce = lambda lo, hi: sent.append((lo, hi))
     red.on_head_ready()
@@ -411,3 +411,53 @@ def test_pk_sampler_reproduces_the_reference_ddp_sampler(golden):
     assert a.global_list() == b.global_list() and not (set(a) & set(b))
     a.set_epoch(4)
     assert a.global_list() != b.global_list()
+
+
+def test_grouped_wgrad_work_plan_covers_every_unit_once():
+    """Host logic of the grouped weight-gradient launch (csrc/gemm_tn_grouped.hip, tng_plan), no GPU: for a range of tile
+    counts / K-step counts / free CUs the plan must (1) give every (row chunk, tile) unit and every column-sum unit to exactly
+    one workgroup iteration, (2) cover all K-steps of every tile with non-empty chunks, (3) never ask for more workgroups than
+    CUs.  The enumeration below is the kernel's own (gemm_tn_group_kernel, 'this workgroup's it-th unit')."""
+    import ctypes
+    from signal_amd import _lib
+    lib = _lib.load()
+    seen_balanced = seen_outside = 0
+    for tiles, ks, grid, cs in [(108, 388, 256, 36), (108, 388, 240, 36), (108, 388, 208, 36), (108, 50, 256, 36), (108, 194, 256, 36),
+                                (108, 774, 256, 36), (27, 388, 256, 36), (108, 388, 256, 0), (9, 50, 256, 0), (1, 1, 256, 0),
+                                (300, 388, 256, 36), (6, 384, 64, 0), (108, 7, 256, 36)]:
+        out = (ctypes.c_int * 8)()
+        _lib.call("sig_debug_tn_plan", tiles, ks, grid, cs, ctypes.cast(out, ctypes.c_void_p))
+        balanced, nsplit, per, sg, n_long, n_short, wgs, inside = list(out)
+        assert 1 <= wgs <= grid, (tiles, ks, grid, list(out))
+        cs_in = cs if inside else 0
+        gemm_units = nsplit * tiles
+        units = gemm_units + cs_in
+        # chunk lengths: all but the last are `per`, the last takes the rest and must not be empty
+        assert per >= 1 and (nsplit - 1) * per < ks, (tiles, ks, grid, list(out))
+        covered = [0] * units
+        for wid in range(wgs):
+            it = 0
+            while True:
+                if not balanced:
+                    u = wid + it * wgs
+                elif wid < n_long:
+                    u = wid if it == 0 else units
+                elif wid < n_long + n_short:
+                    t = it * n_short + (wid - n_long)
+                    u = n_long + t if (it < sg and t < tiles) else units
+                else:
+                    u = gemm_units + (wid - n_long - n_short) + it * (wgs - n_long - n_short)
+                if u >= units:
+                    break
+                covered[u] += 1
+                it += 1
+                assert it < 100000
+        assert all(c == 1 for c in covered), (tiles, ks, grid, cs, list(out), [i for i, c in enumerate(covered) if c != 1][:5])
+        if balanced:
+            seen_balanced += 1
+            assert n_long == (nsplit - 1) * tiles and n_short == -(-tiles // sg) and n_long + n_short <= wgs
+        seen_outside += (cs > 0 and not inside)
+    assert seen_balanced >= 2 and seen_outside >= 1      # the benched shape is balanced; reserved-CU grids leave the column sums out
+    # the benched shape: 2 long chunks of 176 K-steps + a short one of 36 taken 4 tiles per workgroup, 243 + 13 workgroups
+    _lib.call("sig_debug_tn_plan", 108, 388, 256, 36, ctypes.cast(out, ctypes.c_void_p))
+    assert list(out) == [1, 3, 176, 4, 216, 27, 256, 1], list(out)
