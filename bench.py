@@ -175,7 +175,7 @@ def committed_traffic(kernel_key, live_avg_us):
                 prof_us = ent.get("avg_us_rocprofv3")
                 stale = bool(prof_us and live_avg_us and abs(live_avg_us / prof_us - 1) > 0.30)
                 return {"traffic": ent.get("bytes_per_launch"), "traffic_algorithmic": ent.get("algorithmic_bytes_per_launch"),
-                        "traffic_source": f"profiles/{name} <- {d.get('profile_tag')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                        "traffic_source": f"profiles/{name} <- {d.get('profile_tag')}",
                         "traffic_profile_avg_us": prof_us, "traffic_stale": stale}
     return {"traffic": None, "traffic_source": None}
 
