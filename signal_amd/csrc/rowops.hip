@@ -240,8 +240,11 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     SIG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must come together");
     // rows per wave made EQUAL: with a fixed block count 24768 rows over 768 x 4 waves is 8.06 rows per wave -- 6 % of the
     // waves walk a ninth row while the chip idles.  k = rows per wave for ~cap blocks, then exactly ceil(M / (4k)) blocks.
+    // cap = 512 = two resident blocks per CU: the largest grid that is still ONE round.  Measured at M = 24768 (in the train step,
+    // same box, us): 344 blocks (9 rows per wave; the round-2 setting) 58.0 | 387 (8) 54.3 | 443 (7) 51.6 | 516 (6: a second
+    // round starts) 70.1 | 620 (5) 63.4 | 774 (4) 57.4; the column-sum reduce behind it 6.0 -> 6.9 us.
     static int cap = 0, use_part = -1;
-    if (!cap) { const char* e = getenv("SIG_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 384; }
+    if (!cap) { const char* e = getenv("SIG_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 512; }
     if (use_part < 0) { const char* e = getenv("SIG_LN_BWD_ATOMICS"); use_part = e && atoi(e) ? 0 : 1; }
     const int k = sig_ceil_div(M, LN_BWD_WPB * cap);
     int blocks = sig_ceil_div(M, LN_BWD_WPB * (k > 0 ? k : 1));
