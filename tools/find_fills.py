@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 dev = torch.device("cuda:0")
-cfg, model = bench.build_model(dev, sys.argv[1] if len(sys.argv) > 1 else "fwd_sim")
+cfg, model = bench.build_model(dev, "bf16")
 img, vid, cam = bench.synthetic(cfg, 64, dev, 1234)
 if len(sys.argv) > 1 and sys.argv[1] == "train":
     from signal_amd.engine.trainer import TrainStep
