@@ -10,9 +10,10 @@ evaluation.  Ranking statistics (argsort on the device, CMC / AP per query in Nu
 in the reference.  The t-SNE / KDE plotting side effects of the reference's compute() (hard-coded home-directory paths,
 utils/metrics.py:289-297) are intentionally absent.
 
-Parity status: the reference's utils/metrics.py cannot be imported in the build container (seaborn and
-scipy.integrate.simps are missing), so this evaluator is pinned by hand-derived cases (tests/test_metrics_cpu.py) and by an
-independent float64 evaluation (tests/test_eval_gpu.py), not by reference outputs: "parity unpinned"."""
+Parity status: pinned by fixture G10 -- the reference's own eval_func / eval_func_msrv / euclidean_distance (taken out of
+utils/metrics.py's syntax tree by tests/golden/make_golden_metrics.py; the module itself needs seaborn and scipy.integrate.simps and
+cannot be imported) on seeded synthetic retrieval problems, both protocols -- plus hand-derived cases (tests/test_metrics_cpu.py) and an
+independent float64 evaluation (tests/test_eval_gpu.py)."""
 from __future__ import annotations
 
 import numpy as np

@@ -62,6 +62,32 @@ def test_evaluator_distance_matrix_on_the_mfma_gemm_matches_float64(dev):
     assert (np.argsort(distmat, axis=1)[:, :10] == np.argsort(want, axis=1)[:, :10]).mean() > 0.999
 
 
+@pytest.mark.parametrize("tag", ["small", "reid201", "few_gallery", "many_cams"])
+def test_evaluators_on_the_device_vs_reference_fixture(dev, golden, tag):
+    """The evaluator classes end to end on the GPU (features in HBM, distance matrix on the MFMA GEMM, device argsort) against G10:
+    the REFERENCE's eval_func / eval_func_msrv / euclidean_distance run on the same seeded features (tests/golden/make_golden_metrics.py).
+    R1_mAP_eval = camera protocol, R1_mAP = MSVR310 scene protocol."""
+    from signal_amd.utils.metrics import R1_mAP, R1_mAP_eval
+    from tests.golden.make_golden_metrics import make_case
+    g = golden("g10_metrics")
+    seed, nq, ng, ids, cams, scenes, dim, max_rank = (int(v) for v in g[f"{tag}_case"])
+    (qf, qp, qc, qs), (gf, gp, gc, gs) = make_case(seed, nq, ng, ids, cams, scenes, dim)
+    feats = torch.from_numpy(np.concatenate([qf, gf])).to(dev)
+    pids, camids, scn = np.concatenate([qp, gp]), np.concatenate([qc, gc]), np.concatenate([qs, gs])
+    ev = R1_mAP_eval(nq, max_rank=max_rank, feat_norm="yes")
+    ev2 = R1_mAP(nq, max_rank=max_rank, feat_norm="yes")
+    for lo in range(0, nq + ng, 50):
+        ev.update((feats[lo:lo + 50], pids[lo:lo + 50], camids[lo:lo + 50]))
+        ev2.update((feats[lo:lo + 50], pids[lo:lo + 50], camids[lo:lo + 50], scn[lo:lo + 50]))
+    cmc, mAP, distmat, *_ = ev.compute()
+    np.testing.assert_allclose(distmat[:3], g[f"{tag}_dist_rows"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(cmc, g[f"{tag}_cmc"], rtol=0, atol=1e-6)
+    assert mAP == pytest.approx(float(g[f"{tag}_mAP"]), abs=1e-6)
+    cmc_s, mAP_s = ev2.compute()[:2]
+    np.testing.assert_allclose(cmc_s, g[f"{tag}_cmc_msrv"], rtol=0, atol=1e-6)
+    assert mAP_s == pytest.approx(float(g[f"{tag}_mAP_msrv"]), abs=1e-6)
+
+
 def test_checkpoint_round_trip_with_the_ddp_prefix(dev, tmp_path):
     """processor.py:310-321 saves model.state_dict(); under DDP the keys carry 'module.' and Signal.load_param strips it
     (make_model.py:125-130).  state_dict -> add prefix -> load_param into a fresh model -> bit-identical features."""

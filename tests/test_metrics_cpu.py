@@ -186,3 +186,27 @@ def test_clip_visual_loader_is_weights_only_and_resizes(tmp_path):
     torch.save({"visual.proj": Evil()}, bad)
     with pytest.raises(pickle.UnpicklingError):
         load_clip_visual(model, bad, verbose=False)
+
+
+@pytest.mark.parametrize("tag", ["small", "reid201", "few_gallery", "many_cams"])
+def test_eval_funcs_vs_reference_fixture(golden, tag):
+    """G10 (tests/golden/make_golden_metrics.py): CMC / mAP of the REFERENCE's own eval_func and eval_func_msrv (their definitions
+    taken out of utils/metrics.py's syntax tree; the module itself needs seaborn / scipy.integrate.simps and cannot be imported) on
+    seeded synthetic retrieval problems, both protocols.  Here: the same features, distances in float64 on the CPU, signal_amd's
+    rank statistics."""
+    from tests.golden.make_golden_metrics import make_case
+    g = golden("g10_metrics")
+    seed, nq, ng, ids, cams, scenes, dim, max_rank = (int(v) for v in g[f"{tag}_case"])
+    (qf, qp, qc, qs), (gf, gp, gc, gs) = make_case(seed, nq, ng, ids, cams, scenes, dim)
+    qn = torch.nn.functional.normalize(torch.from_numpy(qf), dim=1, p=2).double()
+    gn = torch.nn.functional.normalize(torch.from_numpy(gf), dim=1, p=2).double()
+    dist = (qn.pow(2).sum(1, keepdim=True) + gn.pow(2).sum(1, keepdim=True).t() - 2 * qn @ gn.t()).numpy()
+    np.testing.assert_allclose(dist[:3], g[f"{tag}_dist_rows"], rtol=0, atol=2e-6)       # the reference's f32 addmm_ distances
+    assert abs(dist.sum() - float(g[f"{tag}_dist_sum"])) < 1e-3 * abs(float(g[f"{tag}_dist_sum"]))
+    cmc, mAP = eval_func(dist, qp, gp, qc, gc, max_rank=max_rank)
+    np.testing.assert_allclose(cmc, g[f"{tag}_cmc"], rtol=0, atol=1e-6)
+    assert mAP == pytest.approx(float(g[f"{tag}_mAP"]), abs=1e-9)
+    cmc_s, mAP_s = eval_func_msrv(dist, qp, gp, qc, gc, qs, gs, max_rank=max_rank)
+    np.testing.assert_allclose(cmc_s, g[f"{tag}_cmc_msrv"], rtol=0, atol=1e-6)
+    assert mAP_s == pytest.approx(float(g[f"{tag}_mAP_msrv"]), abs=1e-9)
+    assert not np.allclose(cmc_s, cmc) or mAP_s != mAP      # the two protocols differ on these data
