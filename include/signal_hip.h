@@ -122,6 +122,10 @@ int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols,
 /* n transposes in one launch: table[d] = {src f32*, dst bf16*, rows, cols} as int64, tile_start[d] = index of matrix d's
  * first 64x64 tile in the flattened grid, tile_start[n] = total_tiles. */
 int sig_transpose_cast_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, int dtype, void* stream);
+/* The same for sources that already are 16-bit (the operand mirror sig_adam_step / sig_cast_bf16 maintain): table[d] = {src 16-bit*,
+ * dst 16-bit*, rows, cols}, rows and cols multiples of 64; 16-B loads and stores, a pure permutation of bit patterns (the result equals
+ * cast-then-transpose of the f32 master bit for bit). */
+int sig_transpose16_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, void* stream);
 int sig_colsum_bf16(const uint16_t* a, int lda, int M, int N, float* out, int dtype, void* stream);
 int sig_colsum_f32(const float* a, int lda, int M, int N, float* out, void* stream);
 

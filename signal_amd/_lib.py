@@ -36,6 +36,7 @@ SIGNATURES = {
     "sig_cast_bf16": [_vp, _vp, _sz, _i, _vp],
     "sig_transpose_cast_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "sig_transpose_cast_multi": [_vp, _vp, _i, _i, _i, _vp],
+    "sig_transpose16_multi": [_vp, _vp, _i, _i, _vp],
     "sig_colsum_bf16": [_vp, _i, _i, _i, _vp, _i, _vp],
     "sig_colsum_f32": [_vp, _i, _i, _i, _vp, _vp],
     "sig_im2col": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

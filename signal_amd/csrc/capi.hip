@@ -94,6 +94,9 @@ int sig_cast_bf16(const float* src, uint16_t* dst, size_t n, int dtype, void* st
 int sig_transpose_cast_bf16(const float* src, uint16_t* dst, int rows, int cols, int dtype, void* stream) {
     return sig_launch_transpose_cast_bf16(src, dst, rows, cols, dtype, (hipStream_t)stream);
 }
+int sig_transpose16_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, void* stream) {
+    return sig_launch_transpose16_multi((const long long*)table, tile_start, n, total_tiles, (hipStream_t)stream);
+}
 int sig_transpose_cast_multi(const int64_t* table, const int* tile_start, int n, int total_tiles, int dtype, void* stream) {
     return sig_launch_transpose_cast_multi((const long long*)table, tile_start, n, total_tiles, dtype, (hipStream_t)stream);
 }

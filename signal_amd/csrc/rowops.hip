@@ -332,6 +332,48 @@ __global__ __launch_bounds__(256) void transpose_cast_multi_kernel(const long lo
     for (int c = ty; c < 64; c += 4)
         if (c0 + c < cols && r0 + tx < rows) dst[(size_t)(c0 + c) * rows + r0 + tx] = f2cvt16(tile[tx][c], dt);
 }
+// The same for sources that already ARE 16-bit (the operand mirror the fused Adam refreshes): table[d] = {src 16-bit*, dst 16-bit*,
+// rows, cols}, rows and cols multiples of 64.  16-B loads and 16-B stores (the f32-source kernel above writes 2 B per lane: 3.2 TB/s);
+// a pure permutation of bit patterns, so the result equals cast-then-transpose of the f32 master bit for bit.
+__global__ __launch_bounds__(256) void transpose16_multi_kernel(const long long* __restrict__ table, const int* __restrict__ tile_start, int n) {
+    __shared__ unsigned short tile[64][72];      // row pitch 144 B: the transposed 2-B reads of a lane group spread over the banks
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const bf16_t* src = (const bf16_t*)table[lo * 4 + 0];
+    bf16_t* dst = (bf16_t*)table[lo * 4 + 1];
+    const int rows = (int)table[lo * 4 + 2], cols = (int)table[lo * 4 + 3];
+    const int t = b - tile_start[lo], tx_n = cols >> 6;
+    const int r0 = (t / tx_n) * 64, c0 = (t % tx_n) * 64;
+    const int ch = threadIdx.x & 7, rr = threadIdx.x >> 3;          // 8 chunks of 8 elements x 32 rows per sweep
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = rr + 32 * k;
+        const uint4 v = *(const uint4*)(src + (size_t)(r0 + r) * cols + c0 + ch * 8);
+        *(uint4*)&tile[r][ch * 8] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = rr + 32 * k;                                   // output row = source column
+        unsigned short e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = tile[ch * 8 + i][c];
+        uint4 o;
+        o.x = e[0] | ((unsigned)e[1] << 16); o.y = e[2] | ((unsigned)e[3] << 16);
+        o.z = e[4] | ((unsigned)e[5] << 16); o.w = e[6] | ((unsigned)e[7] << 16);
+        *(uint4*)(dst + (size_t)(c0 + c) * rows + r0 + ch * 8) = o;
+    }
+}
+int sig_launch_transpose16_multi(const long long* table, const int* tile_start, int n, int total_tiles, hipStream_t st) {
+    SIG_CHECK_ARG(table && tile_start && n > 0 && total_tiles > 0, "transpose16_multi: bad arguments");
+    hipLaunchKernelGGL(transpose16_multi_kernel, dim3(total_tiles), dim3(256), 0, st, table, tile_start, n);
+    SIG_CHECK_LAUNCH("transpose16_multi");
+    return 0;
+}
 int sig_launch_transpose_cast_multi(const long long* table, const int* tile_start, int n, int total_tiles, int dt, hipStream_t st) {
     SIG_CHECK_DT(dt, "transpose_cast_multi");
     SIG_CHECK_ARG(table && tile_start && n > 0 && total_tiles > 0, "transpose_cast_multi: bad arguments");

@@ -85,6 +85,7 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
 int sig_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, int dt, hipStream_t st);
 int sig_launch_transpose_cast_bf16(const float* src, bf16_t* dst, int rows, int cols, int dt, hipStream_t st);
 int sig_launch_transpose_cast_multi(const long long* table, const int* tile_start, int n, int total_tiles, int dt, hipStream_t st);
+int sig_launch_transpose16_multi(const long long* table, const int* tile_start, int n, int total_tiles, hipStream_t st);
 int sig_launch_colsum_bf16(const bf16_t* a, int lda, int M, int N, float* out, int dt, hipStream_t st);
 int sig_launch_colsum_f32(const float* a, int lda, int M, int N, float* out, hipStream_t st);
 int sig_launch_im2col(const float* img, bf16_t* out, int nimg, int H, int W, int P, int dt, hipStream_t st);

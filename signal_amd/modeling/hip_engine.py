@@ -321,23 +321,37 @@ class HipPath:
         if cast:
             _lib.call("sig_cast_bf16", fl.data.data_ptr(), fl.op16.data_ptr(), fl.total, self.dt, st)
         if self._tt is None:   # descriptor table of every transposed copy (pointers are stable: flat buffers persist)
+            # sources are the 16-bit operand mirror (just refreshed by the cast above or by the fused Adam): a pure 16-bit
+            # transpose moves half the bytes of cast-and-transpose from the f32 master and gives the same bits
             rows = []
             for name, t in self._transposed.items():
-                src = self._byname[name].data
-                rows.append((src.data_ptr(), t.data_ptr(), src.shape[0], src.numel() // src.shape[0]))
+                src = self._pk(name)
+                src = src.view(src.shape[0], -1)
+                rows.append((src.data_ptr(), t.data_ptr(), src.shape[0], src.shape[1]))
             if self.sim_p is not None:
-                w = self._byname[self._sim_in_w].data
+                w = self._pk(self._sim_in_w)
                 rows.append((w[:512].data_ptr(), self._sim_T["q"].data_ptr(), 512, 512))
                 rows.append((w[512:].data_ptr(), self._sim_T["kv"].data_ptr(), 1024, 512))
+            fast = all(r % 64 == 0 and c % 64 == 0 for _, _, r, c in rows)
             starts, tot = [], 0
             for _, _, r, c in rows:
                 starts.append(tot)
                 tot += ((r + 63) // 64) * ((c + 63) // 64)
             starts.append(tot)
+            if not fast:       # a matrix that is not a multiple of 64 x 64: the general kernel, from the f32 master
+                rows = [(self._byname[name].data.data_ptr(), t.data_ptr(), self._byname[name].shape[0],
+                         self._byname[name].numel() // self._byname[name].shape[0]) for name, t in self._transposed.items()]
+                if self.sim_p is not None:
+                    w = self._byname[self._sim_in_w].data
+                    rows.append((w[:512].data_ptr(), self._sim_T["q"].data_ptr(), 512, 512))
+                    rows.append((w[512:].data_ptr(), self._sim_T["kv"].data_ptr(), 1024, 512))
             self._tt = (torch.tensor(rows, dtype=torch.int64, device=fl.device),
-                        torch.tensor(starts, dtype=torch.int32, device=fl.device), len(rows), tot)
-        table, starts, n, tot = self._tt
-        _lib.call("sig_transpose_cast_multi", table.data_ptr(), starts.data_ptr(), n, tot, self.dt, st)
+                        torch.tensor(starts, dtype=torch.int32, device=fl.device), len(rows), tot, fast)
+        table, starts, n, tot, fast = self._tt
+        if fast:
+            _lib.call("sig_transpose16_multi", table.data_ptr(), starts.data_ptr(), n, tot, st)
+        else:
+            _lib.call("sig_transpose_cast_multi", table.data_ptr(), starts.data_ptr(), n, tot, self.dt, st)
 
     # ------------------------------------------------------------------ backbone
     def _alloc_vit(self, S, B, train):

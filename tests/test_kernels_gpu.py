@@ -430,3 +430,24 @@ def test_gemm_tn_grouped_small_batch_and_fallback(dev):
         o4 = torch.zeros(2304, 768, device=dev)
         ops.gemm_tn_grouped([(p1[:mr2], q1[:mr2], o4)])
         assert rel_err(o4, p1[:mr2].double().t() @ q1[:mr2].double()) < 5e-6, mr2
+
+
+def test_transpose16_multi_is_a_pure_permutation(dev, dt16):
+    """The 16-bit multi-matrix transpose behind the weight repack (after the fused Adam refreshed the operand mirror): bit-identical
+    to torch's transpose of the same 16-bit data, for the block's four weight shapes, the head projection and SIM's 512-wide ones."""
+    from signal_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(9)
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 512), (512, 512), (1024, 512), (64, 128)]
+    srcs = [torch.randn(r, c, generator=g).to(dt16).to(dev) for r, c in shapes]
+    dsts = [torch.zeros(c, r, dtype=dt16, device=dev) for r, c in shapes]
+    rows, starts, tot = [], [], 0
+    for s_, d_ in zip(srcs, dsts):
+        rows.append((s_.data_ptr(), d_.data_ptr(), s_.shape[0], s_.shape[1]))
+        starts.append(tot)
+        tot += (s_.shape[0] // 64) * (s_.shape[1] // 64)
+    starts.append(tot)
+    table = torch.tensor(rows, dtype=torch.int64, device=dev)
+    st = torch.tensor(starts, dtype=torch.int32, device=dev)
+    _lib.call("sig_transpose16_multi", table.data_ptr(), st.data_ptr(), len(rows), tot, torch.cuda.current_stream().cuda_stream)
+    for s_, d_ in zip(srcs, dsts):
+        assert torch.equal(d_, s_.t().contiguous()), tuple(s_.shape)
