@@ -271,9 +271,36 @@ __device__ __forceinline__ void epilogue_nat(const SigGemmNT& p, f32x4_t (&acc)[
     const bool save_u = GELU_FWD && p.aux != nullptr;
     const bool do_sum = CAN_SUM && p.colsum != nullptr;
     f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
+    // Residual rows: `res` may alias `out` (the in-place residual stream), so the compiler keeps every residual load behind the
+    // previous row's store -- 40 dependent HBM round trips per wave.  Each lane reads exactly the addresses it writes later, so the
+    // loads of RES_AHEAD row groups are requested by hand before the first of their stores (the fragment registers are dead here).
+#ifndef SIG_RES_AHEAD
+#define SIG_RES_AHEAD 2
+#endif
+    constexpr int RES_AHEAD = HAS_RES ? SIG_RES_AHEAD : 1;
+    f32x4_t rv[RES_AHEAD][4];
+    auto res_fetch = [&](int i) {
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m_base + i * 16 + g * 4 + e;
+                rv[i % RES_AHEAD][e] = *(const f32x4_t*)(p.res + (size_t)(m < p.M ? m : 0) * p.ldr + n);
+            }
+        }
+    };
+    if constexpr (HAS_RES) {
+#pragma unroll
+        for (int i = 0; i < RES_AHEAD && i < TM; ++i) res_fetch(i);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         uint2 uq[4];
+        f32x4_t rcur[4];
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rcur[e] = rv[i % RES_AHEAD][e];
+            // (the refill for row group i + RES_AHEAD is requested after this group's stores, below)
+        }
         if (GELU_BWD) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -286,7 +313,7 @@ __device__ __forceinline__ void epilogue_nat(const SigGemmNT& p, f32x4_t (&acc)[
             const int m = m_base + i * 16 + g * 4 + e;
             const bool live = m < p.M;
             f32x4_t x = (f32x4_t){acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]} + bias4;
-            if (HAS_RES && live) x += *(const f32x4_t*)(p.res + (size_t)m * p.ldr + n);
+            if constexpr (HAS_RES) { if (live) x += rcur[e]; }
             if (GELU_FWD) {
                 f32x4_t keep = x;
                 if constexpr (QUICK) {
@@ -319,6 +346,9 @@ __device__ __forceinline__ void epilogue_nat(const SigGemmNT& p, f32x4_t (&acc)[
                 else *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + n) = make_uint2(pack2_t<DT>(x[0], x[1]), pack2_t<DT>(x[2], x[3]));   // plain: sc1 on these 8-B stores measured qkv 92 -> 105 us
             }
             if (do_sum && live) csum += x;
+        }
+        if constexpr (HAS_RES) {
+            if (i + RES_AHEAD < TM) res_fetch(i + RES_AHEAD);
         }
     }
     if (do_sum) {
