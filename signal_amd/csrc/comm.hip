@@ -93,10 +93,20 @@ int sig_comm_init_impl(SigComm** out, int rank, int world, const void* id128) {
     c->rank = rank; c->world = world;
     UniqueId id;
     memcpy(&id, id128, sizeof(id));
-    SIG_RCCL_CHECK(r->init(&c->comm, world, id, rank), "comm_init (ncclCommInitRank)");
-    SIG_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking), "comm_init: side stream");
-    SIG_HIP_CHECK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming), "comm_init: event");
-    SIG_HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming), "comm_init: event");
+    int rc = r->init(&c->comm, world, id, rank);
+    if (rc != 0) {
+        sig_set_error("comm_init (ncclCommInitRank): RCCL error %d (%s)", rc, r->errstr ? r->errstr(rc) : "?");
+        c->comm = nullptr;
+        (void)sig_comm_destroy_impl(c);
+        return 3;
+    }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        sig_set_error("comm_init: side stream / events: %s", hipGetErrorString(hipGetLastError()));
+        (void)sig_comm_destroy_impl(c);      // releases whatever was created
+        return 2;
+    }
     *out = c;
     return 0;
 }
