@@ -485,8 +485,9 @@ def test_backward_is_reproducible_run_to_run(dev):
     assert err < 1e-6
 
 
-def test_benched_batch_train_step_big_tiles_vs_small_tiles(dev):
-    """The train step AT THE BENCHED SIZE (RGBNT201, bf16, B = 64: 320x256 / 256x256 NT tiles with their training epilogues --
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_benched_batch_train_step_big_tiles_vs_small_tiles(dev, dtype):
+    """The train step AT THE BENCHED SIZE (RGBNT201, both operand types, B = 64: 320x256 / 256x256 NT tiles with their training epilogues --
     c_fc + saved derivative, GELU' dgrad -- and the grouped weight-gradient kernel) against the same step on the kernels the
     B = 8 oracle comparisons pin (128-row NT tiles, 128x128 weight-gradient tiles).  Same operands, same rounding points,
     another summation order: loss equal to 1e-5, every parameter's gradient cos >= 0.9999, whole gradient >= 0.99999."""
@@ -500,7 +501,7 @@ def test_benched_batch_train_step_big_tiles_vs_small_tiles(dev):
     batch = ({k: v.to(dev) for k, v in img.items()}, vid.to(dev), cam.to(dev))
     res = {}
     for tag, nt, tn in (("big", 0, 0), ("small", 128, 128)):
-        cfg = make_cfg(ocfg, "bf16")
+        cfg = make_cfg(ocfg, dtype)
         cfg.SOLVER.OPTIMIZER_NAME, cfg.SOLVER.BASE_LR = "Adam", 0.0
         model = make_frame(cfg, ocfg.num_classes, ocfg.camera_num, 0)
         model.load_state_dict(sd, strict=False)
@@ -519,6 +520,6 @@ def test_benched_batch_train_step_big_tiles_vs_small_tiles(dev):
     assert abs(l0 - l1) / abs(l1) < 1e-5, (l0, l1)
     worst = min((cos(g0[o:o + n], g1[o:o + n]), k) for k, (o, n) in names.items() if float(g1[o:o + n].norm()) > 1e-6)
     whole = cos(g0, g1)
-    print(f"[B=64 train step, big tiles vs small tiles] loss {l0:.6f} / {l1:.6f}, worst parameter cos {worst[0]:.6f} ({worst[1]}), whole {whole:.7f}")
+    print(f"[B=64 train step {dtype}, big tiles vs small tiles] loss {l0:.6f} / {l1:.6f}, worst parameter cos {worst[0]:.6f} ({worst[1]}), whole {whole:.7f}")
     assert worst[0] > 0.9999, worst
     assert whole > 0.99999, whole
