@@ -1066,7 +1066,11 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
     if (force != 0 && force != 320) tall320 = false;      // (SIG_GEMM_TILE=1: the choice without this kernel, for A/B runs)
     const bool timed = g_prof.on && g_prof.epi == EPI && g_prof.N == p.N && g_prof.K == p.K && g_prof.used + 2 <= g_prof.ev.size();
     if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-    if (tall320) {
+    if (force == 0 && sig_nt192p_eligible(p, EPI, cus)) {
+        p.band = choose_band(p.N >> 8, p.K, 256);
+        const int rc = sig_launch_nt192p(p, EPI, cus, st);
+        if (rc) return rc;
+    } else if (tall320) {
         static bool attr320 = false;
         if (!attr320) {
             (void)hipFuncSetAttribute((const void*)&gemm_nt320_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);

@@ -33,6 +33,10 @@ struct SigGemmNT {
     int dt;            // SIG_DT_BF16 / SIG_DT_F16: type of A, Bt, aux and of 16-bit outputs
 };
 int sig_launch_gemm_nt(const SigGemmNT& p, int epi, hipStream_t st);
+// persistent 192x256 kernel with the store tail of tile n under the main loop of tile n+1 (gemm_nt_persist.hip)
+bool sig_nt192p_eligible(const SigGemmNT& p, int epi, int cus);
+int sig_launch_nt192p(const SigGemmNT& p, int epi, int cus, hipStream_t st);
+int sig_tune_nt_persist_impl(int on);
 #ifndef SIG_PROF_TN256
 #define SIG_PROF_TN256 100   // sig_prof_begin class: gemm_tn256_kernel launches (N = I, K = J; 0 = any shape)
 #endif

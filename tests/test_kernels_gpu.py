@@ -119,6 +119,48 @@ def test_gemm_tn_headline_shapes_vs_fp64(dev, dt16, i, j, reserved):
         lib.sig_tune_reserved_cus(prev)
 
 
+# shapes that reach the persistent 192x256 kernel (whole 192-row tiles, >= 512 tiles, K >= 768 in an even number of K-steps):
+# the benched qkv / c_fc shapes, a K = 1536 loop, and a shape whose XCD ranges are ragged (43 x 12 = 516 tiles)
+PERSIST_SHAPES = [(24768, 2304, 768), (24768, 3072, 768), (8256, 3072, 1536), (12288, 2304, 768)]
+
+
+@pytest.mark.parametrize("m,n,k", PERSIST_SHAPES)
+def test_gemm_nt_persistent_kernel(dev, dt16, m, n, k):
+    """gemm_nt192p_kernel (store tail of tile n under the main loop of tile n+1) against the f32 product of the same operands AND
+    against the one-tile-per-workgroup kernels: every output element is the same K-ordered MFMA chain, so the 16-bit results
+    must be bit-identical; pad rows untouched; two launches agree bit for bit."""
+    from signal_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    T = tol_scale(dt16)
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g)).to(dt16).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05 + torch.linspace(-0.02, 0.03, n)[:, None]).to(dt16).to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    ap = padded(a, ops)
+    ref = a.float() @ w.float().t()
+    pre = ref + bias
+    want = {ops.BF16: ref, ops.BIAS_BF16: pre, ops.BIAS_GELU_BF16: pre * torch.sigmoid(1.702 * pre)}
+    got = {}
+    for persist in (1, 0):
+        prev = lib.sig_tune_nt_persist(persist)
+        try:
+            for epi in want:
+                ob = torch.zeros(ops.pad_rows(m), n, device=dev, dtype=dt16)
+                ops.gemm_nt(ap, w, m, epi, ob, bias=None if epi == ops.BF16 else bias)
+                if persist:
+                    ob2 = torch.zeros_like(ob)
+                    ops.gemm_nt(ap, w, m, epi, ob2, bias=None if epi == ops.BF16 else bias)
+                    assert torch.equal(ob, ob2), "two launches of the persistent kernel differ"
+                assert not bool(ob[m:].abs().any()), "pad rows must stay untouched"
+                got[(persist, epi)] = ob
+        finally:
+            lib.sig_tune_nt_persist(prev)
+    for epi, r in want.items():
+        assert rel_err(got[(1, epi)][:m].float(), r) < 4e-3 * T, epi
+        assert torch.equal(got[(1, epi)], got[(0, epi)]), f"persistent and per-tile kernels differ (epilogue {epi})"
+
+
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
 def test_gemm_nt_epilogues(dev, dt16, nt_tile, m, n, k):
     ops = _ops()
