@@ -276,26 +276,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
 // eligibility and launch -----------------------------------------------------------------------------------------------
 #include <atomic>
 #ifndef SIG_NT_PERSIST_DEFAULT
-#define SIG_NT_PERSIST_DEFAULT 0
+#define SIG_NT_PERSIST_DEFAULT 1
 #endif
 static std::atomic<int> g_persist{-1};      // SIG_NT_PERSIST / sig_tune_nt_persist: 0 = off, 1 = wherever legal
 static int persist_setting() {
     int v = g_persist.load();
     if (v < 0) {
         const char* e = getenv("SIG_NT_PERSIST");
-        v = e ? (atoi(e) != 0) : SIG_NT_PERSIST_DEFAULT;
+        v = e ? atoi(e) : SIG_NT_PERSIST_DEFAULT;
         g_persist = v;
     }
     return v;
 }
 int sig_tune_nt_persist_impl(int on) {
     const int prev = persist_setting();     // (resolves the environment preset first: restoring `prev` keeps it)
-    g_persist = on != 0;
+    g_persist = on < 0 ? 0 : on;
     return prev;
 }
 bool sig_nt192p_eligible(const SigGemmNT& p, int epi, int cus) {
     if (!persist_setting()) return false;
-    const bool epi_ok = epi == SIG_EPI_BF16 || epi == SIG_EPI_BIAS_BF16 || (epi == SIG_EPI_BIAS_GELU_BF16 && p.aux == nullptr);
+    // The QuickGELU forward has a persistent form too (sig_tune_nt_persist(2) admits it), but its ~2.9 k cycles of exp / rcp per
+    // wave and tile sit between two tiles' MFMAs here where the per-tile kernels hide them under their store tail: measured
+    // 119 -> 123 us for c_fc at inference (tools/persist_ab.py), so it stays with the 256x256 / 320x256 kernels.
+    const bool epi_ok = epi == SIG_EPI_BF16 || epi == SIG_EPI_BIAS_BF16 ||
+                        (epi == SIG_EPI_BIAS_GELU_BF16 && p.aux == nullptr && persist_setting() >= 2);
     if (!epi_ok || p.colsum) return false;
     const int nk = p.K >> 6;
     if ((p.N & 255) || (p.K & 63) || nk < 12 || (nk & 1)) return false;

@@ -142,7 +142,7 @@ def test_gemm_nt_persistent_kernel(dev, dt16, m, n, k):
     pre = ref + bias
     want = {ops.BF16: ref, ops.BIAS_BF16: pre, ops.BIAS_GELU_BF16: pre * torch.sigmoid(1.702 * pre)}
     got = {}
-    for persist in (1, 0):
+    for persist in (2, 0):        # 2 = every epilogue that has a persistent form (1, the default, leaves the GELU forward out)
         prev = lib.sig_tune_nt_persist(persist)
         try:
             for epi in want:
@@ -157,8 +157,8 @@ def test_gemm_nt_persistent_kernel(dev, dt16, m, n, k):
         finally:
             lib.sig_tune_nt_persist(prev)
     for epi, r in want.items():
-        assert rel_err(got[(1, epi)][:m].float(), r) < 4e-3 * T, epi
-        assert torch.equal(got[(1, epi)], got[(0, epi)]), f"persistent and per-tile kernels differ (epilogue {epi})"
+        assert rel_err(got[(2, epi)][:m].float(), r) < 4e-3 * T, epi
+        assert torch.equal(got[(2, epi)], got[(0, epi)]), f"persistent and per-tile kernels differ (epilogue {epi})"
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
