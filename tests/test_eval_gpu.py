@@ -144,7 +144,16 @@ def test_do_train_and_do_inference_run_the_reference_loop(dev, tmp_path, caplog)
     train_loader = SyntheticTriplets(batch=4, hw=tuple(ocfg.size_train), num_instances=2, cams=ocfg.camera_num, steps=3, seed=3)
     val_loader = ValLoader(ocfg, n=21, bs=6, seed=50)          # 5 queries + 16 gallery (Rank-10 is logged)
     caplog.set_level(logging.INFO)
-    do_train(cfg, model, center, train_loader, val_loader, optimizer, optimizer_center, scheduler, loss_fn, 5, 0, cfg.MODEL.stageName)
+    # do_train feeds the engine through DevicePrefetcher (H2D of batch i+1 on a side stream under step i): what the engine sees
+    # must be the loader's batches, in order, already on the device
+    seen = []
+    do_train(cfg, model, center, train_loader, val_loader, optimizer, optimizer_center, scheduler, loss_fn, 5, 0, cfg.MODEL.stageName,
+             batch_hook=lambda ep, it, img, vid, cam, view: seen.append(({k: v.clone() for k, v in img.items()}, vid.clone(), cam.clone())))
+    host = list(train_loader)                                   # (SyntheticTriplets is seeded: the same three batches again)
+    assert len(seen) == len(host) == 3
+    for (dimg, dvid, dcam), (himg, hvid, hcam, _, _) in zip(seen, host):
+        assert all(dimg[k].is_cuda and torch.equal(dimg[k].cpu(), himg[k]) for k in ("RGB", "NI", "TI"))
+        assert torch.equal(dvid.cpu(), hvid) and torch.equal(dcam.cpu(), hcam)
     text = caplog.text
     assert "Epoch[1] Iteration[3/3] Loss:" in text and "Validation Results - Epoch: 1" in text and "Best mAP:" in text
     ck = os.path.join(str(tmp_path), "run", cfg.MODEL.NAME + "_1.pth")
