@@ -362,7 +362,6 @@ def main():
         odt = "fp16" if args.dtype == "bf16" else "bf16"
         ts = None
         step = fwd_step = None
-        model.hip = None
         del model
         import gc
         gc.collect()
