@@ -1704,6 +1704,7 @@ float* sig_stream_scratch(hipStream_t st, size_t bytes, int slot) {
                 (void)hipStreamSynchronize(st);
                 (void)hipFree(ents[i].p);
                 if (hipMalloc((void**)&ents[i].p, bytes) != hipSuccess) { ents[i].p = nullptr; ents[i].bytes = 0; return nullptr; }
+                (void)hipMemsetAsync(ents[i].p, 0, bytes, st);      // new scratch starts zero-filled (arrival counters rely on it)
                 ents[i].bytes = bytes;
             }
             return ents[i].p;
@@ -1711,6 +1712,7 @@ float* sig_stream_scratch(hipStream_t st, size_t bytes, int slot) {
     if (n == 32) return nullptr;   // more (device, stream) pairs than slots: the caller falls back to atomics
     float* ptr = nullptr;
     if (hipMalloc((void**)&ptr, bytes) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(ptr, 0, bytes, st);
     ents[n++] = {dev, st, slot, ptr, bytes};
     return ptr;
 }
