@@ -59,6 +59,10 @@ class TrainStep:
         self.stage = cfg.MODEL.stageName if stage is None else stage
         self.loss_fn = loss_fn or make_loss(cfg, num_classes)[0]
         hip = model.hip
+        try:
+            self.loss_fn.hip = hip          # the loss kernels' per-step scratch comes from the engine's arena (layers/make_loss.py)
+        except AttributeError:
+            pass                            # a caller's own callable that takes no attributes: it keeps torch.zeros
         hip.prepare(next(model.parameters()).device)
         # parameters that cannot receive a gradient in this stage keep .grad = None, exactly what autograd leaves the
         # reference with: torch optimizers skip them (no weight decay on W_q/W_k, no moment updates)
@@ -120,6 +124,13 @@ class TrainStep:
     def step(self, img, target, target_cam, target_view=None):
         hip = self.model.hip
         hip.flat.grad.zero_()
+        hip.arena_begin(hip.flat.device)     # ONE fill for every small zero-initialised buffer of the step's head stages
+        try:
+            return self._step(hip, img, target, target_cam, target_view)
+        finally:
+            hip.arena_end()
+
+    def _step(self, hip, img, target, target_cam, target_view):
         if self.reducer is not None:
             self.reducer.broadcast_buffers(self._buffers)    # DDP broadcast_buffers: rank 0's BN running statistics, every forward
         out = self.model(img, label=target, cam_label=target_cam, view_label=target_view, training=True, sge=self.stage)
@@ -145,4 +156,4 @@ class TrainStep:
             self.optimizer.step(scaler=self.scaler)
             self.scaler.update()
         self.last_output = out
-        return loss
+        return loss.detach().clone()         # (the step's scalars live in per-step scratch: the caller gets its own copy)

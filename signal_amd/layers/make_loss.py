@@ -31,17 +31,40 @@ def make_loss(cfg, num_classes):
     eps = 0.1 if cfg.MODEL.IF_LABELSMOOTH == "on" else 0.0
     margin = None if cfg.MODEL.NO_MARGIN else cfg.SOLVER.MARGIN
 
+    # loss_func.hip (set by the training engine): the model's HipPath, whose per-step arena then provides the loss kernels'
+    # zero-filled scratch instead of one torch.zeros launch each
     if sampler == "softmax":
         def loss_func(score, feat, target, target_cam):          # plain cross entropy (make_loss.py:104-106)
             _device_pair(score, feat, target)
-            return reid_loss(score, feat, target, 0.0, 1.0, 0.0, None)
+            return reid_loss(score, feat, target, 0.0, 1.0, 0.0, None, getattr(loss_func, "hip", None))
     elif sampler == "softmax_triplet":
         def loss_func(score, feat, target, target_cam):
             _device_pair(score, feat, target)
-            return reid_loss(score, feat, target, eps, cfg.MODEL.ID_LOSS_WEIGHT, cfg.MODEL.TRIPLET_LOSS_WEIGHT, margin)
+            return reid_loss(score, feat, target, eps, cfg.MODEL.ID_LOSS_WEIGHT, cfg.MODEL.TRIPLET_LOSS_WEIGHT, margin,
+                             getattr(loss_func, "hip", None))
     else:
         raise ValueError(f"expected sampler should be softmax or softmax_triplet but got {sampler}")
     return loss_func, None   # the reference's CenterLoss is built but never used with METRIC_LOSS_TYPE='triplet'
+
+
+class _WeightedSum(torch.autograd.Function):
+    """sum_i w_i * term_i over 0-dim device tensors as two launches forward (stack, dot) and one backward (g * w; the terms'
+    gradients are views of it), instead of one add / multiply kernel per term in each direction."""
+    _w = {}
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        dev = terms[0].device
+        key = (weights, dev)
+        w = _WeightedSum._w.get(key)
+        if w is None:
+            w = _WeightedSum._w[key] = torch.tensor(weights, dtype=torch.float32, device=dev)
+        ctx.w = w
+        return torch.dot(torch.stack([t.reshape(()).float() for t in terms]), w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, *(g * ctx.w).unbind(0))
 
 
 def total_loss(cfg, output, loss_fn, target, target_cam, stage):
@@ -50,11 +73,12 @@ def total_loss(cfg, output, loss_fn, target, target_cam, stage):
     sign = output[0]
     alpha, beta = cfg.MODEL.Gram_Loss_weight, cfg.MODEL.PAT_Loss_weight
     tail = 0 if sign in (1, 2) else (1 if stage == "CLS" else 2)
-    loss = 0
+    terms, weights = [], []
     for i in range(1, len(output) - tail, 2):
-        loss = loss + loss_fn(score=output[i], feat=output[i + 1], target=target, target_cam=target_cam)
+        terms.append(loss_fn(score=output[i], feat=output[i + 1], target=target, target_cam=target_cam))
+        weights.append(1.0)
     if tail == 1:
-        loss = loss + alpha * output[-1]
+        terms.append(output[-1]); weights.append(float(alpha))
     elif tail == 2:
-        loss = loss + alpha * output[-2] + beta * output[-1]
-    return loss
+        terms += [output[-2], output[-1]]; weights += [float(alpha), float(beta)]
+    return _WeightedSum.apply(tuple(weights), *terms)

@@ -444,6 +444,43 @@ class HipPath:
         _lib.call("sig_embed_bwd", d, ref(self.embed_p), ref(ws["embed_a"]), ref(self.embed_g), ws["dx"].data_ptr(),
                   ws["dpre"].data_ptr(), ws["dtok_e"].data_ptr(), None if cam is None else cam.data_ptr(), self.patch, st)
 
+    # ------------------------------------------------------------------ per-step arena of small zero-initialised buffers
+    # The head stages (BNNeck, ReID loss) need a dozen small zero-filled accumulators per training step.  torch.zeros launches a
+    # fill kernel for each (~5 us + a kernel boundary; ~30 per step, tools/find_fills.py).  The training engine arms an arena at
+    # the top of every step: ONE fill over the part that was used, then the buffers are views handed out by a bump pointer.
+    # Outside an armed step (tests, inference, plain autograd use) zeros() is torch.zeros.  Arena views are valid until the next
+    # armed step begins: only per-step scratch may come from here, nothing a caller keeps.
+    _arena = None
+    _arena_pos = 0
+    _arena_hw = 0
+    _arena_armed = False
+    _ids_checked = None       # the label tensor whose two-identity check already ran in this step (reid_head.reid_loss)
+
+    def arena_begin(self, device, floats=1 << 21):
+        self._ids_checked = None
+        if self._arena is None or self._arena.device != device:
+            self._arena = torch.zeros(floats, dtype=F32, device=device)
+            self._arena_hw = 0
+        elif self._arena_hw:
+            self._arena[:self._arena_hw].zero_()
+        self._arena_pos, self._arena_hw, self._arena_armed = 0, 0, True
+
+    def arena_end(self):
+        self._arena_armed = False
+        self._ids_checked = None
+
+    def zeros(self, *shape, device=None):
+        n = 1
+        for d in shape:
+            n *= d
+        n64 = (n + 63) // 64 * 64
+        if self._arena_armed and self._arena_pos + n64 <= self._arena.numel():
+            v = self._arena[self._arena_pos:self._arena_pos + n].view(*shape)
+            self._arena_pos += n64
+            self._arena_hw = max(self._arena_hw, self._arena_pos)
+            return v
+        return torch.zeros(*shape, dtype=F32, device=device if device is not None else self.flat.device)
+
     on_block_grads_ready = None  # hooks for the data-parallel reducer (signal_amd/parallel)
     on_head_grads_ready = None
 
@@ -607,7 +644,11 @@ class SimFn(torch.autograd.Function):
         ws = hip.sim_forward(tok, B, train)
         ctx.hip, ctx.ws, ctx.B, ctx.shape, ctx.lease = hip, ws, B, tokens.shape, _WsLease(ws)
         ctx.acc = hip.shared_dtokens(tokens) if train else None
-        out = ws["t"]["out"][:3 * B].reshape(B, 3 * 512).clone()
+        out = ws["t"]["out"][:3 * B].reshape(B, 3 * 512)
+        # training: handed out in place -- the workspace stays leased until SimFn.backward, which autograd runs after the backward
+        # of everything that consumed `out`; inference returns the workspace at once, so the caller gets a copy
+        if not train:
+            out = out.clone()
         mask = ws["t"]["mask_f"].view(3, B, hip.L - 1).clone()
         ctx.mark_non_differentiable(mask)
         if not train:
@@ -639,8 +680,10 @@ class GamFn(torch.autograd.Function):
         ws = hip.gam_forward(tok, B)
         ctx.hip, ctx.ws, ctx.shape, ctx.lease = hip, ws, tokens.shape, _WsLease(ws)
         ctx.acc = hip.shared_dtokens(tokens) if hip.grad_mode else None
-        out = ws["t"]["loss"][0].clone()
-        if not (hip.grad_mode and any(ctx.needs_input_grad)):   # no backward will come: hand the workspace back now
+        keep = hip.grad_mode and any(ctx.needs_input_grad)
+        # (with a backward to come the workspace stays leased until then: the scalar is handed out in place)
+        out = ws["t"]["loss"][0] if keep else ws["t"]["loss"][0].clone()
+        if not keep:                                            # no backward will come: hand the workspace back now
             ctx.lease.release()
         return out
 
@@ -670,7 +713,7 @@ class LamFn(torch.autograd.Function):
         ws = hip.lam_forward(tok, B, train)
         ctx.hip, ctx.ws, ctx.tok, ctx.lease = hip, ws, tok, _WsLease(ws)
         ctx.acc = hip.shared_dtokens(tok) if train else None
-        out = ws["t"]["loss"][0].clone()
+        out = ws["t"]["loss"][0] if train else ws["t"]["loss"][0].clone()
         if not train:
             ctx.lease.release()
         return out

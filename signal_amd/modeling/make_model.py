@@ -160,15 +160,15 @@ class Signal(nn.Module):
             return ori if not self.use_A else torch.cat([ori, vars_total], dim=-1)
 
         if self.use_A:
-            vars_score = bnneck_classifier(self.bottleneck_var, self.classifier_var, vars_total)
+            vars_score = bnneck_classifier(self.bottleneck_var, self.classifier_var, vars_total, self.hip)
         if self.direct:
             ori = torch.cat([RGB_global, NI_global, TI_global], dim=-1)
-            ori_score = bnneck_classifier(self.bottleneck, self.classifier, ori)
+            ori_score = bnneck_classifier(self.bottleneck, self.classifier, ori, self.hip)
             head = (ori_score, ori)
         else:
-            head = (bnneck_classifier(self.bottleneck_r, self.classifier_r, RGB_global), RGB_global,
-                    bnneck_classifier(self.bottleneck_n, self.classifier_n, NI_global), NI_global,
-                    bnneck_classifier(self.bottleneck_t, self.classifier_t, TI_global), TI_global)
+            head = (bnneck_classifier(self.bottleneck_r, self.classifier_r, RGB_global, self.hip), RGB_global,
+                    bnneck_classifier(self.bottleneck_n, self.classifier_n, NI_global, self.hip), NI_global,
+                    bnneck_classifier(self.bottleneck_t, self.classifier_t, TI_global, self.hip), TI_global)
         if not self.use_A:
             return (1, *head)
         if not self.use_B:
