@@ -46,6 +46,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
     constexpr int HELD = 2 * STAGE;                        // 8 waves x 12 slots x 512 B of parked store units
     constexpr bool HAS_BIAS = EPI == SIG_EPI_BIAS_BF16 || EPI == SIG_EPI_BIAS_GELU_BF16;
     constexpr bool GELU_FWD = EPI == SIG_EPI_BIAS_GELU_BF16;
+    constexpr bool UMUL = EPI == SIG_EPI_DGELU_BF16;          // out = acc * aux (the saved QuickGELU'), + optional column sums
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,49 +120,71 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
 
     // ---- parked store units of the previous tile.  Unit u = 4 i + e is rows i*16 + 4 g + e of this wave's strip
     //      (4 rows x 128 B per instruction); units 0..11 wait in registers, 12..23 in lane-private LDS slots.
+    //      GELU' dgrad (out = acc * aux): the SAME storage carries the next conversion's multiplier in between (see the plan
+    //      in `step`); the conversion multiplies in place.  24 registers + 6 KB of LDS per wave either way.
     u32x2_t hr[12];
     const unsigned hbase = lds0 + HELD + wave * 6144 + lane * 8;
     const unsigned lane_out = (unsigned)((wm + 4 * g) * p.ldo + wn + 4 * fr) * 2u;       // byte offset inside a tile's output
+    const unsigned lane_aux = UMUL ? (unsigned)((wm + 4 * g) * p.ldaux + wn + 4 * fr) * 2u : 0u;
     const unsigned lane_bias = (unsigned)(wn + 4 * fr) * 4u;
-    const size_t ldo2 = (size_t)p.ldo * 2;
+    const size_t ldo2 = (size_t)p.ldo * 2, ldx2 = (size_t)p.ldaux * 2;
     const char* pout = nullptr;                                                            // previous tile's output base (uniform)
+    const char* uin = nullptr;                                                             // this tile's aux base (uniform; GELU' only)
     auto unit_base = [&](const char* tile_out, int u) { return tile_out + (size_t)((u >> 2) * 16 + (u & 3)) * ldo2; };
+    auto aux_base = [&](int u) { return uin + (size_t)((u >> 2) * 16 + (u & 3)) * ldx2; };
+    auto load8 = [&](u32x2_t& dst, const void* uniform_base, unsigned lane_off) {
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(uniform_base) : "memory");
+    };
 
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
 
-    // One K-step.  FIRST: first K-step of a tile (accumulators start from zero).  RU: first of the four register units
-    // drained in this K-step (-1: none).  `lu`: first of the two LDS units drained in this K-step (< 0: none; uniform).
+    // One K-step.  KT = its index inside the tile when < 12 (compile-time: everything that happens beside the MFMAs is a
+    // fixed plan per K-step), -1 for the K-steps beyond the twelfth (K > 768: nothing to drain any more).
     //   bsrc / bval: B panel of the NEXT K-step (same tile or the next one); asrc / aval: A panel of the K-step after it.
-    auto step = [&](int st, auto first_c, auto ru_c, int lu, const bf16_t* bsrc, bool bval, const bf16_t* asrc, bool aval) {
-        constexpr int RU = decltype(ru_c)::value;
-        u32x2_t l0, l1;
-        // P0: outstanding aX,bX (7) + aY (3).  The two LDS units of this K-step are read unconditionally (slot 0 when there
-        // is nothing to drain): an asm output written on one side of a branch makes the compiler merge registers with
-        // copies, and a copy of a register whose ds_read is still in flight copies stale bits.  They sit BEFORE the
-        // fragment reads: the counted waits below only name the newest reads.
-        {
-            const unsigned ad = hbase + (unsigned)((lu >= 0 ? lu : 12) - 12) * 512u;
-            asm volatile("ds_read_b64 %0, %1" : "=v"(l0) : "v"(ad));
-            asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(l1) : "v"(ad));
+    auto step = [&](auto kt_c, int st, const bf16_t* bsrc, bool bval, const bf16_t* asrc, bool aval) {
+        constexpr int KT = decltype(kt_c)::value;
+        constexpr bool FIRST = KT == 0;
+        // the plan: K-steps 0..2 the twelve register units leave (four each), 3..5 the twelve LDS units (four each).  GELU'
+        // dgrad: from K-step 6 on the 24 unit registers are free; K-step 6 requests the aux values of the LDS units INTO them,
+        // K-step 7 moves them to the (emptied) slots, K-step 8 requests the register units' own aux values.  Two batches of
+        // twelve loads, each right behind its K-step's DMA pieces: vector memory retires in order, so the next K-step's stage
+        // boundary waits for them -- HBM latency against the DMA's L2 latency -- and two such boundaries cost less than six.
+        constexpr int RU = (KT >= 0 && KT <= 2) ? 4 * KT : -1;
+        constexpr int LU = (KT >= 3 && KT <= 5) ? 12 + 4 * (KT - 3) : -1;
+        constexpr bool ULS = UMUL && KT == 6, UWS = UMUL && KT == 7, ULH = UMUL && KT == 8;
+        constexpr int NLOAD = (ULS || ULH) ? 12 : 0, NSTORE = (RU >= 0 ? 4 : 0) + (LU >= 0 ? 4 : 0);
+        u32x2_t l[4];
+        // P0: outstanding aX,bX (7) + aY (3).  The LDS units of this K-step are read whether or not there is a previous tile
+        // (an asm output written on one side of a branch makes the compiler merge registers with copies, and a copy of a
+        // register whose ds_read is still in flight copies stale bits); they sit BEFORE the fragment reads: the counted waits
+        // below only name the newest reads.
+        if constexpr (LU >= 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(l[q]) : "v"(hbase), "n"((LU - 12) * 512 + q * 512));
         }
         rd_a(st, 0, H1{}, aY);
         if (bval) { dma_b(0, bsrc, st ^ 1); dma_b(1, bsrc, st ^ 1); dma_b(2, bsrc, st ^ 1); dma_b(3, bsrc, st ^ 1); }
+        if constexpr (ULS || ULH) {      // (behind the K-step's last DMA piece: the boundary wait below leaves exactly these in flight)
+#pragma unroll
+            for (int q = 0; q < 12; ++q) load8(hr[q], aux_base((ULS ? 12 : 0) + q), lane_aux);
+        }
         PP_WAIT7(3, aX, bX);
-        asm volatile("" : "+v"(l0), "+v"(l1));      // (landed with the wait above: they are older than aX, bX)
+        if constexpr (LU >= 0) asm volatile("" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]));      // (landed: older than aX, bX)
         __builtin_amdgcn_sched_barrier(0);
-        mma(first_c, 0, aX, bX);
+        mma(std::integral_constant<bool, FIRST>{}, 0, aX, bX);
         __builtin_amdgcn_sched_barrier(0);
         // P1: outstanding aY (3) + aX,bY (7)
         rd_a(st, 1, H0{}, aX);
         rd_b(st, 1, bY);
         PP_WAIT3(7, aY);
         __builtin_amdgcn_sched_barrier(0);
-        mma(first_c, 1, aY, bX);
+        mma(std::integral_constant<bool, FIRST>{}, 1, aY, bX);
         __builtin_amdgcn_sched_barrier(0);
-        // the K-step's stores: behind its last DMA piece (so the boundary wait below can leave them in flight)
+        // the K-step's stores and aux requests: behind its last DMA piece, so that the boundary wait below can leave exactly
+        // them in flight (vector-memory operations retire in order)
         if constexpr (RU >= 0) {
             if (pout) {
 #pragma unroll
@@ -174,22 +197,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
         __builtin_amdgcn_sched_barrier(0);
         mma(F_{}, 0, aX, bY);
         __builtin_amdgcn_sched_barrier(0);
-        if (lu >= 0) {
-            pp_store8(unit_base(pout, lu), lane_out, l0);
-            pp_store8(unit_base(pout, lu + 1), lane_out, l1);
+        if constexpr (LU >= 0) {
+            if (pout) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pp_store8(unit_base(pout, LU + q), lane_out, l[q]);
+            }
         }
-        // stage boundary: this wave's DMA pieces of the next stage landed (exactly the stores above are younger: vmcnt
-        // retires in order), all its LDS reads of this stage returned
+        // stage boundary: this wave's DMA pieces of the next stage landed, all its LDS reads of this stage returned
         // (the vmcnt statements carry no register operands: nothing to merge across the branches)
-        if (RU >= 0 && pout) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (lu >= 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NSTORE && pout) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD + NSTORE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aY[0]), "+v"(aY[1]), "+v"(aY[2])::"memory");
         __builtin_amdgcn_s_barrier();
         // P3
         rd_a(st ^ 1, 0, H0{}, aX);      // (unconditional: after the workgroup's last K-step these fragments are never used)
         rd_b(st ^ 1, 0, bX);
         if (aval) { dma_a(0, asrc, st); dma_a(1, asrc, st); dma_a(2, asrc, st); }
+        if constexpr (UWS) {            // requested one K-step ago, behind that K-step's DMA pieces: landed with THIS boundary wait
+            asm volatile("" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]), "+v"(hr[4]), "+v"(hr[5]), "+v"(hr[6]), "+v"(hr[7]),
+                         "+v"(hr[8]), "+v"(hr[9]), "+v"(hr[10]), "+v"(hr[11]));
+#pragma unroll
+            for (int q = 0; q < 12; ++q) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(hbase), "v"(hr[q]), "n"(q * 512) : "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma(F_{}, 1, aY, bY);
         __builtin_amdgcn_sched_barrier(0);
@@ -212,52 +241,112 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
 #pragma unroll
     for (int j = 0; j < 3; ++j) dma_a(j, acur + 64, 1);
 
-    using RN = std::integral_constant<int, -1>;
     for (int t = 0; t < ntl; ++t) {
         const bool has_next = t + 1 < ntl;
         int m1 = 0, n1 = 0;
         if (has_next) tile_base(slot + (t + 1) * spx, m1, n1);
         const bf16_t* anext = p.A + (size_t)m1 * p.lda;
         const bf16_t* bnext = p.Bt + (size_t)n1 * p.ldb;
+        if constexpr (UMUL) uin = (const char*)p.aux + ((size_t)m0 * p.ldaux + n0) * 2;
         // bias of this tile's columns: requested by hand ahead of K-step 0's DMA pieces (older than them, so K-step 0's
         // boundary wait covers it); a compiler-tracked load would be waited for with vmcnt(0) at its first use -- the
         // tile's end, where the next tile's first stages are in flight
         f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (HAS_BIAS) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bias4) : "v"(lane_bias), "s"(p.bias + n0) : "memory");
-        // K-steps 0..2: the twelve register units of the previous tile (four per K-step)
-        step(0, T_{}, std::integral_constant<int, 0>{}, -1, bcur + 64, true, acur + 128, true);
+        // the twelve planned K-steps (needs nk >= 12); the last two K-steps of the tile request the next tile's first stages
+        auto run = [&](auto kt_c) {
+            constexpr int KT = decltype(kt_c)::value;
+            const bool b_in = KT + 1 < nk, a_in = KT + 2 < nk;
+            const bf16_t* bsrc = b_in ? bcur + (KT + 1) * 64 : bnext;
+            const bf16_t* asrc = a_in ? acur + (KT + 2) * 64 : anext + (KT + 2 - nk) * 64;
+            step(kt_c, KT & 1, bsrc, b_in || has_next, asrc, a_in || has_next);
+        };
+        run(std::integral_constant<int, 0>{});
         if constexpr (HAS_BIAS) asm volatile("" : "+v"(bias4));
-        step(1, F_{}, std::integral_constant<int, 4>{}, -1, bcur + 128, true, acur + 192, true);
-        step(0, F_{}, std::integral_constant<int, 8>{}, -1, bcur + 192, true, acur + 256, true);
-        // K-steps 3..nk-1: its twelve LDS units, two per K-step (3..8); the last two K-steps request the next tile's stages
-        for (int kt = 3; kt < nk; ++kt) {
-            const int lu = (pout && kt < 9) ? 12 + 2 * (kt - 3) : -1;
+        run(std::integral_constant<int, 1>{});
+        run(std::integral_constant<int, 2>{});
+        run(std::integral_constant<int, 3>{});
+        run(std::integral_constant<int, 4>{});
+        run(std::integral_constant<int, 5>{});
+        run(std::integral_constant<int, 6>{});
+        run(std::integral_constant<int, 7>{});
+        run(std::integral_constant<int, 8>{});
+        run(std::integral_constant<int, 9>{});
+        if constexpr (UMUL) {           // (the register units' aux values, requested in K-step 8: landed with K-step 9's boundary wait)
+            asm volatile("" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]), "+v"(hr[4]), "+v"(hr[5]), "+v"(hr[6]), "+v"(hr[7]),
+                         "+v"(hr[8]), "+v"(hr[9]), "+v"(hr[10]), "+v"(hr[11]));
+        }
+        run(std::integral_constant<int, 10>{});
+        run(std::integral_constant<int, 11>{});
+        for (int kt = 12; kt < nk; ++kt) {
             const bool b_in = kt + 1 < nk, a_in = kt + 2 < nk;
             const bf16_t* bsrc = b_in ? bcur + (kt + 1) * 64 : bnext;
             const bf16_t* asrc = a_in ? acur + (kt + 2) * 64 : anext + (kt + 2 - nk) * 64;
-            step(kt & 1, F_{}, RN{}, lu, bsrc, b_in || has_next, asrc, a_in || has_next);
+            step(std::integral_constant<int, -1>{}, kt & 1, bsrc, b_in || has_next, asrc, a_in || has_next);
         }
         // ---- the tile is complete: finish it in registers and park it (every unit of the previous tile left in K-steps 0..8)
         const char* tout = (const char*)p.out + ((size_t)m0 * p.ldo + n0) * 2;
+        f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
+        // one store unit: rows i*16 + 4g + e, this lane's four columns; `w` = its aux values (GELU' dgrad only)
+        auto finish_unit = [&](int i, int e, u32x2_t w) -> u32x2_t {
+            f32x4_t x = (f32x4_t){acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]} + bias4;
+            if constexpr (GELU_FWD) {
+                f32x4_t sg, tt = x * -2.4554669595930156f;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+                for (int c = 0; c < 4; ++c) tt[c] = __builtin_amdgcn_exp2f(tt[c]);
+                tt += 1.0f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f32x4_t x = (f32x4_t){acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]} + bias4;
-                if constexpr (GELU_FWD) {
-                    f32x4_t sg, tt = x * -2.4554669595930156f;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) tt[c] = __builtin_amdgcn_exp2f(tt[c]);
-                    tt += 1.0f;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) sg[c] = __builtin_amdgcn_rcpf(tt[c]);
-                    x *= sg;
-                }
-                const u32x2_t v = {pack2_t<DT>(x[0], x[1]), pack2_t<DT>(x[2], x[3])};
-                const int u = i * 4 + e;
-                if (u < 12) hr[u] = v;
-                else asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(hbase), "v"(v), "n"((u - 12) * 512) : "memory");
+                for (int c = 0; c < 4; ++c) sg[c] = __builtin_amdgcn_rcpf(tt[c]);
+                x *= sg;
             }
+            if constexpr (UMUL) {
+                x[0] *= cvt16f_t<DT>((bf16_t)(w[0] & 0xffff)); x[1] *= cvt16f_t<DT>((bf16_t)(w[0] >> 16));
+                x[2] *= cvt16f_t<DT>((bf16_t)(w[1] & 0xffff)); x[3] *= cvt16f_t<DT>((bf16_t)(w[1] >> 16));
+                csum += x;
+            }
+            return (u32x2_t){pack2_t<DT>(x[0], x[1]), pack2_t<DT>(x[2], x[3])};
+        };
+        // LDS units first in program order for the GELU' dgrad: their aux values are read back two units at a time, the next
+        // pair requested before the current one is multiplied (24 live registers for all twelve at once spilled the parked
+        // units -- and a spill of a register that an asm load has not filled yet stores stale bits)
+        u32x2_t ua[2] = {{0u, 0u}, {0u, 0u}}, ub[2] = {{0u, 0u}, {0u, 0u}};
+        if constexpr (UMUL) {
+            asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(ua[0]) : "v"(hbase));
+            asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(ua[1]) : "v"(hbase));
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) hr[u] = finish_unit(u >> 2, u & 3, hr[u]);
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+            u32x2_t(&cur)[2] = (pr & 1) ? ub : ua;
+            u32x2_t(&nxt)[2] = (pr & 1) ? ua : ub;
+            if constexpr (UMUL) {
+                if (pr + 1 < 6) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(nxt[0]) : "v"(hbase), "n"((2 * pr + 2) * 512));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(nxt[1]) : "v"(hbase), "n"((2 * pr + 3) * 512));
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cur[0]), "+v"(cur[1]));      // all but the two just requested
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int u = 12 + 2 * pr + k;
+                const u32x2_t v = finish_unit(u >> 2, u & 3, cur[k]);
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(hbase), "v"(v), "n"((2 * pr + k) * 512) : "memory");
+            }
+        }
+        if constexpr (UMUL) {
+            if (p.colsum) {      // bias-gradient by-product: column sums of what was just produced (f32, before rounding)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float tsum = csum[c];
+                    tsum += __shfl_xor(tsum, 16, 64);
+                    tsum += __shfl_xor(tsum, 32, 64);
+                    if (g == 0) atomicAdd(p.colsum + n0 + wn + 4 * fr + c, tsum);
+                }
+            }
+        }
         pout = tout;
         m0 = m1; n0 = n1;
         acur = anext; bcur = bnext;
@@ -298,11 +387,12 @@ bool sig_nt192p_eligible(const SigGemmNT& p, int epi, int cus) {
     // The QuickGELU forward has a persistent form too (sig_tune_nt_persist(2) admits it), but its ~2.9 k cycles of exp / rcp per
     // wave and tile sit between two tiles' MFMAs here where the per-tile kernels hide them under their store tail: measured
     // 119 -> 123 us for c_fc at inference (tools/persist_ab.py), so it stays with the 256x256 / 320x256 kernels.
-    const bool epi_ok = epi == SIG_EPI_BF16 || epi == SIG_EPI_BIAS_BF16 ||
+    const bool epi_ok = epi == SIG_EPI_BF16 || epi == SIG_EPI_BIAS_BF16 || epi == SIG_EPI_DGELU_BF16 ||
                         (epi == SIG_EPI_BIAS_GELU_BF16 && p.aux == nullptr && persist_setting() >= 2);
-    if (!epi_ok || p.colsum) return false;
+    if (!epi_ok || (p.colsum && epi != SIG_EPI_DGELU_BF16)) return false;
     const int nk = p.K >> 6;
     if ((p.N & 255) || (p.K & 63) || nk < 12 || (nk & 1)) return false;
+    if (epi == SIG_EPI_DGELU_BF16 && (nk != 12 || !p.aux || (p.ldaux & 3))) return false;     // its aux plan is twelve K-steps long
     if (p.M % 192) return false;                               // whole row tiles only (24768 = 129 x 192): no row predicates
     const int tiles = (p.M / 192) * (p.N >> 8);
     return tiles >= 2 * cus;                                   // a launch of several tiles per CU
@@ -326,6 +416,8 @@ int sig_launch_nt192p(const SigGemmNT& p, int epi, int cus, hipStream_t st) {
         case SIG_EPI_BIAS_BF16: return h ? launch_192p<SIG_EPI_BIAS_BF16, SIG_DT_F16>(p, cus, st) : launch_192p<SIG_EPI_BIAS_BF16, SIG_DT_BF16>(p, cus, st);
         case SIG_EPI_BIAS_GELU_BF16:
             return h ? launch_192p<SIG_EPI_BIAS_GELU_BF16, SIG_DT_F16>(p, cus, st) : launch_192p<SIG_EPI_BIAS_GELU_BF16, SIG_DT_BF16>(p, cus, st);
+        case SIG_EPI_DGELU_BF16:
+            return h ? launch_192p<SIG_EPI_DGELU_BF16, SIG_DT_F16>(p, cus, st) : launch_192p<SIG_EPI_DGELU_BF16, SIG_DT_BF16>(p, cus, st);
     }
     sig_set_error("nt192p: epilogue %d has no persistent form", epi);
     return 1;

@@ -141,16 +141,23 @@ def test_gemm_nt_persistent_kernel(dev, dt16, m, n, k):
     ref = a.float() @ w.float().t()
     pre = ref + bias
     want = {ops.BF16: ref, ops.BIAS_BF16: pre, ops.BIAS_GELU_BF16: pre * torch.sigmoid(1.702 * pre)}
+    uu = None
+    if k == 768:        # the GELU' dgrad (out = acc * aux, + column sums = the c_fc bias gradient): its plan is twelve K-steps long
+        uu = torch.randn(m, n, generator=g).to(dt16).to(dev)
+        want[ops.DGELU_BF16] = ref * uu.float()
     got = {}
     for persist in (2, 0):        # 2 = every epilogue that has a persistent form (1, the default, leaves the GELU forward out)
         prev = lib.sig_tune_nt_persist(persist)
         try:
             for epi in want:
+                kw = dict(bias=None if epi in (ops.BF16, ops.DGELU_BF16) else bias)
+                if epi == ops.DGELU_BF16:       # (its column-sum by-product, the c_fc bias gradient, is only reachable through
+                    kw["aux"] = padded(uu, ops)   #  sig_block_bwd: covered by the B = 64 train-step test against the oracle)
                 ob = torch.zeros(ops.pad_rows(m), n, device=dev, dtype=dt16)
-                ops.gemm_nt(ap, w, m, epi, ob, bias=None if epi == ops.BF16 else bias)
+                ops.gemm_nt(ap, w, m, epi, ob, **kw)
                 if persist:
                     ob2 = torch.zeros_like(ob)
-                    ops.gemm_nt(ap, w, m, epi, ob2, bias=None if epi == ops.BF16 else bias)
+                    ops.gemm_nt(ap, w, m, epi, ob2, **kw)
                     assert torch.equal(ob, ob2), "two launches of the persistent kernel differ"
                 assert not bool(ob[m:].abs().any()), "pad rows must stay untouched"
                 got[(persist, epi)] = ob
