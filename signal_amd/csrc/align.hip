@@ -3,6 +3,8 @@
 // each DAS block, which run on the bf16 MFMA GEMM (gemm_bf16.hip) from the host composite in vit.hip.
 //
 // tokens f32 [S*L, 512]: row (m*B+b)*L is the CLS of modality m / sample b, rows +1.. its Lp = h*w patches.
+#include <mutex>
+
 #include "sig_common.h"
 #include "sig_kernels.h"
 
@@ -199,11 +201,10 @@ int sig_launch_gam_fwd(const float* tokens, int B, int L, const float* temp, flo
     hipLaunchKernelGGL(gam_dots_kernel, dim3(sig_ceil_div(B * B + B, 4)), dim3(256), 0, st, fh, B, lv, la, vec);
     SIG_CHECK_LAUNCH("gam_dots");
     const int lds = (B * B + 8 * B) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_done;
+    std::call_once(attr_done, [] {
         (void)hipFuncSetAttribute((const void*)gam_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (128 * 128 + 8 * 128) * 4);
-        attr_done = true;
-    }
+        });
     hipLaunchKernelGGL(gam_loss_kernel, dim3(1), dim3(1024), lds, st, lv, la, vec, temp, B, loss, coef);
     SIG_CHECK_LAUNCH("gam_loss");
     return 0;

@@ -7,6 +7,8 @@
 // tile already is the B operand of O^T = V^T P^T -- no LDS round trip for P.  V^T fragments are fetched with
 // ds_read_b64_tr_b16 from the row-major V image.  Row max / sum are two xor-shuffles across the 4 lane
 // groups that share a query.
+#include <mutex>
+
 #include "sig_common.h"
 #include "sig_kernels.h"
 
@@ -479,12 +481,11 @@ template <int DT>
 static void launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int S, int L,
                             int H, hipStream_t st) {
     const int lds = 4 * ATB_ROWS * 128 + 2 * 160 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_done;
+    std::call_once(attr_done, [] {
         (void)hipFuncSetAttribute((const void*)&attn_bwd_kernel<true, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)&attn_bwd_kernel<false, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+        });
     if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL((attn_bwd_kernel<true, DT>), dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
     else hipLaunchKernelGGL((attn_bwd_kernel<false, DT>), dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
 }

@@ -56,6 +56,7 @@ int sig_gemm_tn_grouped(const SigTnJobDesc* jobs, int n, int Mr, int dtype, void
         j[k].P = jobs[k].P; j[k].Q = jobs[k].Q; j[k].out = jobs[k].out;
         j[k].ldp = jobs[k].ldp; j[k].ldq = jobs[k].ldq; j[k].ldo = jobs[k].ldo; j[k].I = jobs[k].I; j[k].J = jobs[k].J;
         j[k].colsum = jobs[k].colsum;
+        j[k].cs_rows = 0;          // public contract: P's pad rows are zero, the column sums run over all Mr rows
     }
     return sig_launch_gemm_tn_grouped(j, n, Mr, dtype, (hipStream_t)stream);
 }

@@ -11,6 +11,8 @@
 // same symbols.  A single-GPU user never loads it.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "sig_kernels.h"
 
 namespace {
@@ -31,14 +33,16 @@ struct Rccl {
     CommDestroyFn destroy = nullptr;
     GetErrorStringFn errstr = nullptr;
 };
+static char g_rccl_err[256] = "symbols missing";     // why the library could not be bound (captured ONCE: dlerror() clears itself)
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;                        // reached from the caller's and from autograd's thread
+    std::call_once(once, [] {
         for (const char* name : {"librccl.so.1", "librccl.so"}) {
             r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.h) break;
+            const char* e = dlerror();
+            if (e) snprintf(g_rccl_err, sizeof(g_rccl_err), "%s", e);
         }
         if (r.h) {
             r.get_id = (GetUniqueIdFn)dlsym(r.h, "ncclGetUniqueId");
@@ -47,7 +51,7 @@ Rccl* rccl() {
             r.destroy = (CommDestroyFn)dlsym(r.h, "ncclCommDestroy");
             r.errstr = (GetErrorStringFn)dlsym(r.h, "ncclGetErrorString");
         }
-    }
+    });
     return (r.h && r.get_id && r.init && r.allreduce && r.destroy) ? &r : nullptr;
 }
 }  // namespace
@@ -80,7 +84,7 @@ struct SigComm {
 int sig_comm_unique_id_impl(void* id128) {
     SIG_CHECK_ARG(id128, "comm_unique_id: null pointer");
     Rccl* r = rccl();
-    SIG_CHECK_ARG(r, "comm_unique_id: librccl.so.1 not loadable (%s)", dlerror() ? dlerror() : "symbols missing");
+    SIG_CHECK_ARG(r, "comm_unique_id: librccl.so.1 not loadable (%s)", g_rccl_err);
     SIG_RCCL_CHECK(r->get_id((UniqueId*)id128), "comm_unique_id");
     return 0;
 }
@@ -88,7 +92,7 @@ int sig_comm_unique_id_impl(void* id128) {
 int sig_comm_init_impl(SigComm** out, int rank, int world, const void* id128) {
     SIG_CHECK_ARG(out && id128 && world >= 1 && rank >= 0 && rank < world, "comm_init: bad arguments (rank %d of %d)", rank, world);
     Rccl* r = rccl();
-    SIG_CHECK_ARG(r, "comm_init: librccl.so.1 not loadable");
+    SIG_CHECK_ARG(r, "comm_init: librccl.so.1 not loadable (%s)", g_rccl_err);
     SigComm* c = new SigComm();
     c->rank = rank; c->world = world;
     UniqueId id;

@@ -1010,6 +1010,7 @@ static int free_cus() {
 }
 int sig_free_cus() { return free_cus(); }
 int sig_tune_reserved_cus_impl(int n) {
+    (void)free_cus();                            // resolves the SIG_RESERVED_CUS preset first: restoring `prev` keeps it
     const int cur = g_reserved_cus, prev = cur < 0 ? 0 : cur;
     g_reserved_cus = n < 0 ? 0 : (n > 192 ? 192 : n);
     return prev;
@@ -1018,6 +1019,7 @@ int sig_tune_reserved_cus_impl(int n) {
 // SIG_GEMM_TILE=<128|256|320> / sig_tune_gemm_tile(): pin the NT tile wherever that kernel is legal (tests, A/B runs)
 static std::atomic<int> g_force_tile{-1};
 int sig_tune_gemm_tile_impl(int tile) {
+    if (g_force_tile < 0) { const char* e = getenv("SIG_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }   // preset first: restoring `prev` keeps it
     const int cur = g_force_tile, prev = cur < 0 ? 0 : cur;
     g_force_tile = tile;
     return prev;
@@ -1071,11 +1073,10 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
         const int rc = sig_launch_nt192p(p, EPI, cus, st);
         if (rc) return rc;
     } else if (tall320) {
-        static bool attr320 = false;
-        if (!attr320) {
+        static std::once_flag attr320;
+        std::call_once(attr320, [] {
             (void)hipFuncSetAttribute((const void*)&gemm_nt320_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-            attr320 = true;
-        }
+            });
         // one round of the chip: every tile runs at once and the CUs walk k in step, so what an XCD's L2 shares is what its
         // tiles have in common at the same k -- all column tiles of a row tile on one XCD read the A panel once (band =
         // all columns: FETCH of the qkv dgrad 342 -> 114 MB of A; 70.5 -> 68 us, c_fc dgrad 91 -> 88.5); with several
@@ -1083,22 +1084,20 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
         p.band = t320 <= cus ? (p.N >> 8) : choose_band(p.N >> 8, p.K, 256);
         hipLaunchKernelGGL((gemm_nt320_kernel<EPI, DT>), dim3(t320), dim3(512), 147456, st, p, mp);
     } else if (big) {
-        static bool attr256 = false;
-        if (!attr256) {
+        static std::once_flag attr256;
+        std::call_once(attr256, [] {
             (void)hipFuncSetAttribute((const void*)&gemm_nt256_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-            attr256 = true;
-        }
+            });
         p.band = choose_band(p.N >> 8, p.K, 256);
         // (the GELU' dgrad stages a quarter of the saved pre-activation tile in the 32 KB beyond the two operand stages)
         const int lds256 = EPI == SIG_EPI_DGELU_BF16 ? 163840 : 131072;
         hipLaunchKernelGGL((gemm_nt256_kernel<EPI, DT>), dim3((mp >> 8) * (p.N >> 8)), dim3(512), lds256, st, p);
     } else {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static std::once_flag attr_done;
+        std::call_once(attr_done, [] {
             (void)hipFuncSetAttribute((const void*)&gemm_nt_kernel<EPI, 128, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
             (void)hipFuncSetAttribute((const void*)&gemm_nt_kernel<EPI, 160, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
-            attr_done = true;
-        }
+            });
         p.band = choose_band(p.N >> 7, p.K, 128);
         // 160-row tiles when they need fewer rounds of the chip's 512 slots per unit of work (1.25x a 128-row tile) and
         // their last tile stays inside the 128-row padding of the operand buffers
@@ -1722,6 +1721,7 @@ static float* tn_workspace(hipStream_t st, size_t bytes) { return sig_stream_scr
 // with f32 atomics, one launch per weight; 256 = the 256x256 kernel, one launch per weight; 0 = default (grouped per block)
 static std::atomic<int> g_force_tn{-1};
 int sig_tune_tn_path_impl(int path) {
+    (void)sig_tn_path();                         // resolves the SIG_GEMM_TN_TILE preset first: restoring `prev` keeps it
     const int cur = g_force_tn, prev = cur < 0 ? 0 : cur;
     g_force_tn = path;
     return prev;
@@ -1738,11 +1738,10 @@ static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {
     SIG_CHECK_ARG((p.I & 127) == 0 && (p.J & 127) == 0 && p.I > 0 && p.J > 0, "gemm_tn: I=%d, J=%d must be multiples of 128", p.I, p.J);
     SIG_CHECK_ARG((p.ldp & 7) == 0 && (p.ldq & 7) == 0 && p.ldp >= p.I && p.ldq >= p.J && p.ldo >= p.J, "gemm_tn: bad leading dimension");
     SIG_CHECK_ARG(p.P && p.Q && p.out, "gemm_tn: null operand");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::once_flag attr_done;
+    std::call_once(attr_done, [] {
         (void)hipFuncSetAttribute((const void*)&gemm_tn_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_done = true;
-    }
+        });
     const int ksteps = p.Mr >> 6;
     if (g_force_tn < 0) { const char* e = getenv("SIG_GEMM_TN_TILE"); g_force_tn = e ? atoi(e) : 0; }
     const int force = g_force_tn;
@@ -1753,12 +1752,11 @@ static int launch_tn(const SigGemmTN& p_in, hipStream_t st) {
     if (force == 128) big = false;
     if (force == 256) big = can256;
     if (big) {
-        static bool attr256 = false;
-        if (!attr256) {
+        static std::once_flag attr256;
+        std::call_once(attr256, [] {
             (void)hipFuncSetAttribute((const void*)&gemm_tn256_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             (void)hipFuncSetAttribute((const void*)&gemm_tn256x16_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            attr256 = true;
-        }
+            });
         const int tiles = (p.I >> 8) * (p.J >> 8);
         int split = p.split > 0 ? p.split : free_cus() / tiles;      // one block per CU, one round
         if (split < 1) split = 1;

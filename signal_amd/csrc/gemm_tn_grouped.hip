@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_group_kernel(SigTnGroup p) {
             // 512 threads = 64 rows x 8 column groups of 8; a thread owns 8 columns and every 64th row
             const int cg = tid & 7, rr = tid >> 3;
             const bf16_t* src = job.P + c0 + cg * 8;
-            const int rows = p.ks * 64;
+            const int rows = job.cs_rows > 0 ? job.cs_rows : p.ks * 64;
             float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int r = rr; r < rows; r += 512) {             // 8 rows (128 KB per CU) in flight: ~60 GB/s per CU at HBM latency
                 uint4 v[8];
@@ -460,6 +460,9 @@ static bool tng_fits(const SigTnJob* jobs, int njobs, int Mr, int* tiles_out) {
         const SigTnJob& j = jobs[k];
         if (!j.P || !j.Q || !j.out || j.I <= 0 || j.J <= 0 || (j.I & 255) || (j.J & 255)) return false;
         if ((j.ldp & 7) || (j.ldq & 7) || j.ldp < j.I || j.ldq < j.J || j.ldo < j.J) return false;
+        // 16-B LDS-DMA pieces on P and Q, uint4 column-sum loads on P, float4 read-modify-write on dW when ldo % 4 == 0: a
+        // column-sliced view whose base is not 16-B aligned takes the per-weight path instead
+        if (((uintptr_t)j.P & 15) || ((uintptr_t)j.Q & 15) || (((j.ldo & 3) == 0) && ((uintptr_t)j.out & 15))) return false;
         tiles += (j.I >> 8) * (j.J >> 8);
     }
     *tiles_out = tiles;
@@ -604,7 +607,8 @@ static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int t
     }
     if (timed) sig_prof_tn_stop(st, flops);    // (the whole operation: with the two-kernel form the reduce is inside the bracket too)
     if (cs_job >= 0 && g.cs_job < 0)       // the plan left the column sums out of the launch: their own pass
-        return sig_launch_colsum_bf16(jobs[cs_job].P, jobs[cs_job].ldp, Mr, jobs[cs_job].I, jobs[cs_job].colsum, DT, st);
+        return sig_launch_colsum_bf16(jobs[cs_job].P, jobs[cs_job].ldp, jobs[cs_job].cs_rows > 0 ? jobs[cs_job].cs_rows : Mr, jobs[cs_job].I,
+                                      jobs[cs_job].colsum, DT, st);
     return 0;
 }
 
@@ -649,7 +653,7 @@ int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, 
             if (rc || cs_units) return rc;
             for (int k = 0; k < njobs; ++k)
                 if (jobs[k].colsum) {
-                    const int rc2 = sig_launch_colsum_bf16(jobs[k].P, jobs[k].ldp, Mr, jobs[k].I, jobs[k].colsum, dt, st);
+                    const int rc2 = sig_launch_colsum_bf16(jobs[k].P, jobs[k].ldp, jobs[k].cs_rows > 0 ? jobs[k].cs_rows : Mr, jobs[k].I, jobs[k].colsum, dt, st);
                     if (rc2) return rc2;
                 }
             return 0;
@@ -665,7 +669,7 @@ int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, 
         const int rc = sig_launch_gemm_tn(p, st);
         if (rc) return rc;
         if (jobs[k].colsum) {
-            const int rc2 = sig_launch_colsum_bf16(jobs[k].P, jobs[k].ldp, Mr, jobs[k].I, jobs[k].colsum, dt, st);
+            const int rc2 = sig_launch_colsum_bf16(jobs[k].P, jobs[k].ldp, jobs[k].cs_rows > 0 ? jobs[k].cs_rows : Mr, jobs[k].I, jobs[k].colsum, dt, st);
             if (rc2) return rc2;
         }
     }

@@ -68,6 +68,8 @@ struct SigTnJob {
     float* out;       // dW [I, ldo] f32, +=
     int ldp, ldq, ldo, I, J;
     float* colsum;    // optional [I]: += column sums of P over the rows (the bias gradient that goes with dW), else nullptr
+    int cs_rows;      // rows the column sums run over (0 = all Mr): the VALID rows when P's pad rows may hold stale data -- the GEMM
+                      // itself is protected by Q's zero pad rows, a column sum of P is not
 };
 int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, hipStream_t st);
 int sig_debug_tn_plan_impl(int tiles, int ks, int grid, int cs_units, int* out);

@@ -137,10 +137,12 @@ int sig_block_bwd(const SigVitDims* d, const SigBlockParams* p, const SigBlockAc
     // LayerNorm backward below), so they go as ONE stream-K launch + one reduce (gemm_tn_grouped.hip) ----
     {
         const SigTnJob jobs[4] = {
-            {s->dqkv, a->h1, g->w_in, 3 * D, D, D, 3 * D, D, g->b_in}, // attn.in_proj_weight [3D, D] + in_proj_bias = column sums of dqkv
-            {s->dx_mid_b, a->attn, g->w_out, D, D, D, D, D, nullptr},  // attn.out_proj.weight [D, D]
-            {s->du, a->h2, g->w_fc, F, D, D, F, D, nullptr},           // mlp.c_fc.weight      [F, D]
-            {dx_out_b, a->g, g->w_proj, D, F, F, D, F, nullptr},       // mlp.c_proj.weight    [D, F]
+            // (in_proj: its bias gradient = column sums of dqkv over the M VALID rows -- a caller's reused scratch may leave stale pad rows,
+            //  which the GEMM is protected from by h1's zero pad rows but a column sum is not)
+            {s->dqkv, a->h1, g->w_in, 3 * D, D, D, 3 * D, D, g->b_in, M}, // attn.in_proj_weight [3D, D] + in_proj_bias
+            {s->dx_mid_b, a->attn, g->w_out, D, D, D, D, D, nullptr, 0},  // attn.out_proj.weight [D, D]
+            {s->du, a->h2, g->w_fc, F, D, D, F, D, nullptr, 0},           // mlp.c_fc.weight      [F, D]
+            {dx_out_b, a->g, g->w_proj, D, F, F, D, F, nullptr, 0},       // mlp.c_proj.weight    [D, F]
         };
         RUN(sig_launch_gemm_tn_grouped(jobs, 4, Mp, dt, st));
     }

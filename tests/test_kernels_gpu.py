@@ -481,6 +481,31 @@ def test_gemm_tn_grouped_small_batch_and_fallback(dev):
         assert rel_err(o4, p1[:mr2].double().t() @ q1[:mr2].double()) < 5e-6, mr2
 
 
+def test_gemm_tn_grouped_without_workspace_falls_back(dev):
+    """when the library-owned workspace for the partial tiles cannot be had (hipMalloc failure, scratch table full)
+    the grouped launch must not fail the whole block backward: it falls back to one launch per weight (SIG_TN_NO_WS=1 forces
+    that path; the switch is read once per process, hence the child process)."""
+    import subprocess, sys, os
+    code = r"""
+import torch, sys
+sys.path.insert(0, %r)
+from signal_amd import ops
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(11)
+mr = 3200
+p1, q1 = torch.randn(mr, 2304, generator=g).bfloat16().to(dev), torch.randn(mr, 768, generator=g).bfloat16().to(dev)
+p2, q2 = torch.randn(mr, 768, generator=g).bfloat16().to(dev), torch.randn(mr, 768, generator=g).bfloat16().to(dev)
+o1, o2, c1 = torch.zeros(2304, 768, device=dev), torch.zeros(768, 768, device=dev), torch.zeros(2304, device=dev)
+ops.gemm_tn_grouped([(p1, q1, o1, c1), (p2, q2, o2)])
+rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+e = max(rel(o1, p1.double().t() @ q1.double()), rel(o2, p2.double().t() @ q2.double()), rel(c1, p1.double().sum(0)))
+print('MAXERR', e)
+assert e < 5e-6
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, SIG_TN_NO_WS="1"))
+    assert r.returncode == 0 and "MAXERR" in r.stdout, r.stderr[-2000:]
+
+
 def test_transpose16_multi_is_a_pure_permutation(dev, dt16):
     """The 16-bit multi-matrix transpose behind the weight repack (after the fused Adam refreshed the operand mirror): bit-identical
     to torch's transpose of the same 16-bit data, for the block's four weight shapes, the head projection and SIM's 512-wide ones."""
