@@ -7,6 +7,8 @@
 // tile already is the B operand of O^T = V^T P^T -- no LDS round trip for P.  V^T fragments are fetched with
 // ds_read_b64_tr_b16 from the row-major V image.  Row max / sum are two xor-shuffles across the 4 lane
 // groups that share a query.
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "sig_common.h"
@@ -477,6 +479,300 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward for L = 16 * 8 + 1 (every shipped geometry: 128 patches + the class token).  With nine 16-row tiles the
+// ninth is 94 % padding: 17 of the 81 (query tile, key tile) pairs are almost empty, and nine tasks per pass on three
+// waves leave the block's time at three tasks per pass.  Here the first 128 rows are EIGHT clean tiles on FOUR waves (two
+// tasks per wave and pass) and row 128 -- `x` below -- is handled beside the matrix cores:
+//   column x of S / dP (every query against key x) and row x (query x against every key): 4 x 129 dot products of 64 on
+//   the VALU, one matrix per wave; from them P[:,x], dS[:,x], P[x,:], dS[x,:];
+//   dQ[x] = sum_j dS[x,j] K[j],  dK[x] = sum_i dS[i,x] Q[i],  dV[x] = sum_i P[i,x] dO[i]: three 64-wide reductions over
+//   129 rows, one per wave;
+//   the rank-1 terms dQ[i] += dS[i,x] k_x, dK[j] += dS[x,j] q_x, dV[j] += P[x,j] dO_x are added to the MFMA accumulators of
+//   pass A / pass B just before they are stored (16 FMAs per lane and tile).
+// Everything else (dual-use LDS images, passes A and B, in-register dS) is the kernel above with 8 tiles.
+// ------------------------------------------------------------------------------------------------
+#define ATX_NT 8
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int S, int H) {
+    constexpr int L = 16 * ATX_NT + 1, XR = 16 * ATX_NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;
+    char* sK = smem + ATB_ROWS * 128;
+    char* sV = smem + 2 * ATB_ROWS * 128;
+    char* sG = smem + 3 * ATB_ROWS * 128;                 // dO
+    float* sLse = (float*)(smem + 4 * ATB_ROWS * 128);    // [160] lse * log2(e)
+    float* sDel = sLse + 160;                             // [160] delta = rowsum(dO * O) * scale
+    float* colS = sDel + 160;                             // [132] q_i . k_x  -> P[i,x]
+    float* colD = colS + 132;                             // [132] dO_i . v_x -> dS[i,x]
+    float* rowS = colD + 132;                             // [132] q_x . k_j  -> P[x,j]
+    float* rowD = rowS + 132;                             // [132] dO_x . v_j -> dS[x,j]
+    const int s = blockIdx.x / H, h = blockIdx.x - s * H;
+    const int Dm = H * 64, D3 = 3 * Dm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* base = qkv + (size_t)s * L * D3 + h * 64;
+    const bf16_t* obase = out + (size_t)s * L * Dm + h * 64;
+    const bf16_t* gbase = dout + (size_t)s * L * Dm + h * 64;
+
+    // ---- staging: 144 rows x 8 chunks = 1152 16-B chunks per image, 256 threads, 5 sweeps (the last one half empty) ----
+    constexpr int SWEEPS = (ATB_ROWS * 8 + 255) / 256;
+    uint4 lq[SWEEPS], lk[SWEEPS], lv[SWEEPS], lg[SWEEPS], lo[SWEEPS];
+    float llse[SWEEPS];
+#pragma unroll
+    for (int it = 0; it < SWEEPS; ++it) {
+        const int c = tid + it * 256, r = c >> 3, ch = c & 7;
+        lq[it] = lk[it] = lv[it] = lg[it] = lo[it] = make_uint4(0, 0, 0, 0);
+        llse[it] = 0.f;
+        if (r < L) {
+            lq[it] = *(const uint4*)(base + (size_t)r * D3 + ch * 8);
+            lk[it] = *(const uint4*)(base + (size_t)r * D3 + Dm + ch * 8);
+            lv[it] = *(const uint4*)(base + (size_t)r * D3 + 2 * Dm + ch * 8);
+            lg[it] = *(const uint4*)(gbase + (size_t)r * Dm + ch * 8);
+            lo[it] = *(const uint4*)(obase + (size_t)r * Dm + ch * 8);
+            if (ch == 0) llse[it] = lse[((size_t)s * H + h) * L + r];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < SWEEPS; ++it) {
+        const int c = tid + it * 256, r = c >> 3, ch = c & 7;
+        if (c < ATB_ROWS * 8) {
+            const int off = d_off(r, ch);
+            *(uint4*)(sQ + off) = lq[it];
+            *(uint4*)(sK + off) = lk[it];
+            *(uint4*)(sV + off) = lv[it];
+            *(uint4*)(sG + off) = lg[it];
+        }
+        const uint32_t gw[4] = {lg[it].x, lg[it].y, lg[it].z, lg[it].w}, ow[4] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w};
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d += cvt16f_t<DT>((bf16_t)(gw[e] & 0xffff)) * cvt16f_t<DT>((bf16_t)(ow[e] & 0xffff));
+            d += cvt16f_t<DT>((bf16_t)(gw[e] >> 16)) * cvt16f_t<DT>((bf16_t)(ow[e] >> 16));
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (ch == 0 && c < ATB_ROWS * 8) {
+            sDel[r] = d * 0.125f;
+            sLse[r] = r < L ? llse[it] * 1.4426950408889634f : INFINITY;
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, g = lane >> 4;
+    const int tq = fr >> 2, tp = fr & 3;
+    const float scale = 0.125f, c2 = scale * 1.4426950408889634f;
+
+    // ---- row / column x, step 1: the 4 x 129 raw dot products, one operand pair per wave ----
+    {
+        const char* rows_img = wave == 0 ? sQ : wave == 1 ? sG : wave == 2 ? sK : sV;     // the 129 rows ...
+        const char* vec_img = wave == 0 ? sK : wave == 1 ? sV : wave == 2 ? sQ : sG;      // ... against row x of this image
+        float* dst = wave == 0 ? colS : wave == 1 ? colD : wave == 2 ? rowS : rowD;
+        uint4 xw[8];                           // row x of the other operand, 16-bit as staged (converted on the fly)
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) xw[ch] = *(const uint4*)(vec_img + d_off(XR, ch));
+#pragma unroll 1
+        for (int r = lane; r < L; r += 64) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const uint4 w4 = *(const uint4*)(rows_img + d_off(r, ch));
+                const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w}, x[4] = {xw[ch].x, xw[ch].y, xw[ch].z, xw[ch].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0 = __builtin_fmaf(cvt16f_t<DT>((bf16_t)(w[e] & 0xffff)), cvt16f_t<DT>((bf16_t)(x[e] & 0xffff)), a0);
+                    a1 = __builtin_fmaf(cvt16f_t<DT>((bf16_t)(w[e] >> 16)), cvt16f_t<DT>((bf16_t)(x[e] >> 16)), a1);
+                }
+            }
+            dst[r] = a0 + a1;
+        }
+    }
+    __syncthreads();
+    // ---- step 2: probabilities and dS of column x (per query i) and row x (per key j), in place ----
+    if (tid < L) {
+        const float lx = sLse[XR], dx = sDel[XR];
+        const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(colS[tid], c2, -sLse[tid]));
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(rowS[tid], c2, -lx));
+        const float dc = pc * __builtin_fmaf(colD[tid], scale, -sDel[tid]);
+        const float dr = pr * __builtin_fmaf(rowD[tid], scale, -dx);
+        colS[tid] = pc; colD[tid] = dc; rowS[tid] = pr; rowD[tid] = dr;
+    }
+    __syncthreads();
+    // ---- step 3: the three outputs of row x -- dQ[x] = sum_j dS[x,j] K[j], dK[x] = sum_i dS[i,x] Q[i], dV[x] = sum_i P[i,x] dO[i]
+    //      (the (x, x) term is inside: column x and row x meet there) -- one per wave; a lane owns 4 columns and every 4th row
+    if (wave < 3) {
+        const float* wv = wave == 0 ? rowD : wave == 1 ? colD : colS;
+        const char* img = wave == 0 ? sK : wave == 1 ? sQ : sG;
+        const int rq = lane >> 4, c4 = lane & 15;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int r = rq; r < L; r += 4) {
+            const float wgt = wv[r];
+            const uint2 m2 = *(const uint2*)(img + d_off(r, c4 >> 1) + ((c4 & 1) << 3));
+            a[0] = __builtin_fmaf(wgt, cvt16f_t<DT>((bf16_t)(m2.x & 0xffff)), a[0]);
+            a[1] = __builtin_fmaf(wgt, cvt16f_t<DT>((bf16_t)(m2.x >> 16)), a[1]);
+            a[2] = __builtin_fmaf(wgt, cvt16f_t<DT>((bf16_t)(m2.y & 0xffff)), a[2]);
+            a[3] = __builtin_fmaf(wgt, cvt16f_t<DT>((bf16_t)(m2.y >> 16)), a[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] += __shfl_xor(a[e], 16, 64);
+            a[e] += __shfl_xor(a[e], 32, 64);
+        }
+        if (rq == 0) {
+            bf16_t* o = dqkv + ((size_t)s * L + XR) * D3 + wave * Dm + h * 64 + c4 * 4;
+            *(uint2*)o = make_uint2(pack2_t<DT>(a[0], a[1]), pack2_t<DT>(a[2], a[3]));
+        }
+    }
+
+    // ------------------------------ pass A: dQ of rows 0..127 (a wave owns query tiles wave, wave + 4) ------------------------------
+#pragma unroll 1
+    for (int qt = wave; qt < ATX_NT; qt += 4) {
+        const int q = qt * 16 + fr;
+        bf16x8_t qf[2], gf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = *(const bf16x8_t*)(sQ + d_off(q, (ks << 2) | g));
+            gf[ks] = *(const bf16x8_t*)(sG + d_off(q, (ks << 2) | g));
+        }
+        const float lq2 = sLse[q], dqs = sDel[q];
+        f32x4_t ds[ATX_NT];
+#pragma unroll
+        for (int kt = 0; kt < ATX_NT; ++kt) {
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(sK + d_off(kt * 16 + fr, (ks << 2) | g));
+                const bf16x8_t vf = *(const bf16x8_t*)(sV + d_off(kt * 16 + fr, (ks << 2) | g));
+                a = mfma16<DT>(kf, qf[ks], a);  // S^T
+                b = mfma16<DT>(vf, gf[ks], b);  // dP^T
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -lq2));
+                a[e] = pv * __builtin_fmaf(b[e], scale, -dqs);
+            }
+            ds[kt] = a;
+        }
+        // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < ATX_NT / 2; ++kk) {
+            const f32x4_t p0 = ds[2 * kk], p1 = ds[2 * kk + 1];
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+            pk.w[0] = pack2_t<DT>(p0[0], p0[1]); pk.w[1] = pack2_t<DT>(p0[2], p0[3]);
+            pk.w[2] = pack2_t<DT>(p1[0], p1[1]); pk.w[3] = pack2_t<DT>(p1[2], p1[3]);
+            const bf16x8_t pf = pk.v;
+            const int r0 = 32 * kk + 4 * g + tq;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int chunk = 2 * dt + (tp >> 1);
+                const bf16x4_t v0 = lds_tr16(sK + d_off(r0, chunk) + ((tp & 1) << 3));
+                const bf16x4_t v1 = lds_tr16(sK + d_off(r0 + 16, chunk) + ((tp & 1) << 3));
+                const bf16x8_t kf = (bf16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[dt] = mfma16<DT>(kf, pf, o[dt]);
+            }
+        }
+        // + dS[q, x] k_x: lane (fr, g) holds columns dt*16 + 4g .. +3 of query fr
+        {
+            const float dsx = colD[q];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint2 m2 = *(const uint2*)(sK + d_off(XR, 2 * dt + (g >> 1)) + ((g & 1) << 3));
+                o[dt][0] = __builtin_fmaf(dsx, cvt16f_t<DT>((bf16_t)(m2.x & 0xffff)), o[dt][0]);
+                o[dt][1] = __builtin_fmaf(dsx, cvt16f_t<DT>((bf16_t)(m2.x >> 16)), o[dt][1]);
+                o[dt][2] = __builtin_fmaf(dsx, cvt16f_t<DT>((bf16_t)(m2.y & 0xffff)), o[dt][2]);
+                o[dt][3] = __builtin_fmaf(dsx, cvt16f_t<DT>((bf16_t)(m2.y >> 16)), o[dt][3]);
+            }
+        }
+        store_rows16<DT>(o, dqkv + ((size_t)s * L + q) * D3 + h * 64, true, g);
+    }
+
+    // ------------------------------ pass B: dK, dV of rows 0..127 (a wave owns key tiles wave, wave + 4) ------------------------------
+#pragma unroll 1
+    for (int kt = wave; kt < ATX_NT; kt += 4) {
+        const int key = kt * 16 + fr;
+        bf16x8_t kf[2], vf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[ks] = *(const bf16x8_t*)(sK + d_off(key, (ks << 2) | g));
+            vf[ks] = *(const bf16x8_t*)(sV + d_off(key, (ks << 2) | g));
+        }
+        f32x4_t dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 2      // (fully unrolled the two accumulator sets and four k-steps' fragments spill, as in the nine-tile kernel)
+        for (int qq = 0; qq < ATX_NT / 2; ++qq) {  // query tiles (2qq, 2qq+1) = one 32-deep k-step
+            uint32_t pw[4], sw[4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int qt = 2 * qq + half;
+                f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8_t qf = *(const bf16x8_t*)(sQ + d_off(qt * 16 + fr, (ks << 2) | g));
+                    const bf16x8_t gf = *(const bf16x8_t*)(sG + d_off(qt * 16 + fr, (ks << 2) | g));
+                    a = mfma16<DT>(qf, kf[ks], a);  // S  [row q][col key]
+                    b = mfma16<DT>(gf, vf[ks], b);  // dP [row q][col key]
+                }
+                const f32x4_t l4 = *(const f32x4_t*)(sLse + qt * 16 + 4 * g), d4 = *(const f32x4_t*)(sDel + qt * 16 + 4 * g);
+                float pv[4], dsv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -l4[e]));
+                    dsv[e] = pv[e] * __builtin_fmaf(b[e], scale, -d4[e]);
+                }
+                pw[half * 2] = pack2_t<DT>(pv[0], pv[1]); pw[half * 2 + 1] = pack2_t<DT>(pv[2], pv[3]);
+                sw[half * 2] = pack2_t<DT>(dsv[0], dsv[1]); sw[half * 2 + 1] = pack2_t<DT>(dsv[2], dsv[3]);
+            }
+            union { uint32_t w[4]; bf16x8_t v; } pu, su;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pu.w[e] = pw[e]; su.w[e] = sw[e]; }
+            const bf16x8_t pf = pu.v, sf = su.v;
+            const int r0 = 32 * qq + 4 * g + tq;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int chunk = 2 * dt + (tp >> 1);
+                const bf16x4_t g0 = lds_tr16(sG + d_off(r0, chunk) + ((tp & 1) << 3));
+                const bf16x4_t g1 = lds_tr16(sG + d_off(r0 + 16, chunk) + ((tp & 1) << 3));
+                const bf16x4_t q0 = lds_tr16(sQ + d_off(r0, chunk) + ((tp & 1) << 3));
+                const bf16x4_t q1 = lds_tr16(sQ + d_off(r0 + 16, chunk) + ((tp & 1) << 3));
+                const bf16x8_t gT = (bf16x8_t){g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                const bf16x8_t qT = (bf16x8_t){q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+                dv[dt] = mfma16<DT>(gT, pf, dv[dt]);
+                dk[dt] = mfma16<DT>(qT, sf, dk[dt]);
+            }
+        }
+        // + dS[x, key] q_x and P[x, key] dO_x: lane (fr, g) holds columns dt*16 + 4g .. +3 of key fr
+        {
+            const float rds = rowD[key], rp = rowS[key];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int off = d_off(XR, 2 * dt + (g >> 1)) + ((g & 1) << 3);
+                const uint2 q2 = *(const uint2*)(sQ + off), g2 = *(const uint2*)(sG + off);
+                dk[dt][0] = __builtin_fmaf(rds, cvt16f_t<DT>((bf16_t)(q2.x & 0xffff)), dk[dt][0]);
+                dk[dt][1] = __builtin_fmaf(rds, cvt16f_t<DT>((bf16_t)(q2.x >> 16)), dk[dt][1]);
+                dk[dt][2] = __builtin_fmaf(rds, cvt16f_t<DT>((bf16_t)(q2.y & 0xffff)), dk[dt][2]);
+                dk[dt][3] = __builtin_fmaf(rds, cvt16f_t<DT>((bf16_t)(q2.y >> 16)), dk[dt][3]);
+                dv[dt][0] = __builtin_fmaf(rp, cvt16f_t<DT>((bf16_t)(g2.x & 0xffff)), dv[dt][0]);
+                dv[dt][1] = __builtin_fmaf(rp, cvt16f_t<DT>((bf16_t)(g2.x >> 16)), dv[dt][1]);
+                dv[dt][2] = __builtin_fmaf(rp, cvt16f_t<DT>((bf16_t)(g2.y & 0xffff)), dv[dt][2]);
+                dv[dt][3] = __builtin_fmaf(rp, cvt16f_t<DT>((bf16_t)(g2.y >> 16)), dv[dt][3]);
+            }
+        }
+        bf16_t* krow = dqkv + ((size_t)s * L + key) * D3 + Dm + h * 64;
+        store_rows16<DT>(dk, krow, true, g);
+        store_rows16<DT>(dv, krow + Dm, true, g);
+    }
+}
+
 template <int DT>
 static void launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int S, int L,
                             int H, hipStream_t st) {
@@ -486,6 +782,15 @@ static void launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* 
         (void)hipFuncSetAttribute((const void*)&attn_bwd_kernel<true, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void*)&attn_bwd_kernel<false, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         });
+    static int x1 = -1;       // SIG_ATTN_BWD_X1=0: the nine-tile kernel also at L = 129 (A/B runs)
+    if (x1 < 0) { const char* e = getenv("SIG_ATTN_BWD_X1"); x1 = e ? atoi(e) : 1; }
+    if (x1 && L == 16 * ATX_NT + 1) {
+        const int ldsx = lds + 4 * 132 * 4;
+        static std::once_flag attr_x1;
+        std::call_once(attr_x1, [ldsx] { (void)hipFuncSetAttribute((const void*)&attn_bwd_x1_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsx); });
+        hipLaunchKernelGGL((attn_bwd_x1_kernel<DT>), dim3(S * H), dim3(256), ldsx, st, qkv, out, dout, lse, dqkv, S, H);
+        return;
+    }
     if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL((attn_bwd_kernel<true, DT>), dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
     else hipLaunchKernelGGL((attn_bwd_kernel<false, DT>), dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);
 }

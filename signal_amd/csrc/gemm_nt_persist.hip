@@ -392,7 +392,11 @@ bool sig_nt192p_eligible(const SigGemmNT& p, int epi, int cus) {
     if (!epi_ok || (p.colsum && epi != SIG_EPI_DGELU_BF16)) return false;
     const int nk = p.K >> 6;
     if ((p.N & 255) || (p.K & 63) || nk < 12 || (nk & 1)) return false;
-    if (epi == SIG_EPI_DGELU_BF16 && (nk != 12 || !p.aux || (p.ldaux & 3))) return false;     // its aux plan is twelve K-steps long
+    if (epi == SIG_EPI_DGELU_BF16) {
+        static int dgelu_on = -1;      // SIG_NT_PERSIST_DGELU=0: the GELU' dgrad stays with the 256x256 kernel (A/B runs)
+        if (dgelu_on < 0) { const char* e = getenv("SIG_NT_PERSIST_DGELU"); dgelu_on = e ? atoi(e) : 1; }
+        if (!dgelu_on || nk != 12 || !p.aux || (p.ldaux & 3)) return false;                     // its aux plan is twelve K-steps long
+    }
     if (p.M % 192) return false;                               // whole row tiles only (24768 = 129 x 192): no row predicates
     const int tiles = (p.M / 192) * (p.N >> 8);
     return tiles >= 2 * cus;                                   // a launch of several tiles per CU
