@@ -627,115 +627,155 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
         }
     }
 
-    // ------------------------------ pass A: dQ of rows 0..127 (a wave owns query tiles wave, wave + 4) ------------------------------
-#pragma unroll 1
-    for (int qt = wave; qt < ATX_NT; qt += 4) {
-        const int q = qt * 16 + fr;
-        bf16x8_t qf[2], gf[2];
+    // ------------------------------ pass A: dQ of rows 0..127 ------------------------------
+    // A wave owns query tiles (wave, wave + 4) and walks the keys ONCE for both: every K / V fragment and every transposed K
+    // fragment read from LDS feeds two MFMAs instead of one (the arithmetic phases sit on LDS reads, profiles/r03_experiments.md).
+    {
+        const int qa[2] = {wave * 16 + fr, (wave + 4) * 16 + fr};
+        bf16x8_t qf[2][2], gf[2][2];
+        float lq2[2], dqs[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = *(const bf16x8_t*)(sQ + d_off(q, (ks << 2) | g));
-            gf[ks] = *(const bf16x8_t*)(sG + d_off(q, (ks << 2) | g));
-        }
-        const float lq2 = sLse[q], dqs = sDel[q];
-        f32x4_t ds[ATX_NT];
-#pragma unroll
-        for (int kt = 0; kt < ATX_NT; ++kt) {
-            f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sK + d_off(kt * 16 + fr, (ks << 2) | g));
-                const bf16x8_t vf = *(const bf16x8_t*)(sV + d_off(kt * 16 + fr, (ks << 2) | g));
-                a = mfma16<DT>(kf, qf[ks], a);  // S^T
-                b = mfma16<DT>(vf, gf[ks], b);  // dP^T
+                qf[t][ks] = *(const bf16x8_t*)(sQ + d_off(qa[t], (ks << 2) | g));
+                gf[t][ks] = *(const bf16x8_t*)(sG + d_off(qa[t], (ks << 2) | g));
+            }
+            lq2[t] = sLse[qa[t]];
+            dqs[t] = sDel[qa[t]];
+        }
+        f32x4_t ds[2][ATX_NT];
+#pragma unroll
+        for (int kt = 0; kt < ATX_NT; ++kt) {
+            bf16x8_t kf[2], vf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[ks] = *(const bf16x8_t*)(sK + d_off(kt * 16 + fr, (ks << 2) | g));
+                vf[ks] = *(const bf16x8_t*)(sV + d_off(kt * 16 + fr, (ks << 2) | g));
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -lq2));
-                a[e] = pv * __builtin_fmaf(b[e], scale, -dqs);
+            for (int t = 0; t < 2; ++t) {
+                f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    a = mfma16<DT>(kf[ks], qf[t][ks], a);  // S^T
+                    b = mfma16<DT>(vf[ks], gf[t][ks], b);  // dP^T
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -lq2[t]));
+                    a[e] = pv * __builtin_fmaf(b[e], scale, -dqs[t]);
+                }
+                ds[t][kt] = a;
             }
-            ds[kt] = a;
         }
         // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
-        f32x4_t o[4];
+        f32x4_t o[2][4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < ATX_NT / 2; ++kk) {
-            const f32x4_t p0 = ds[2 * kk], p1 = ds[2 * kk + 1];
-            union { uint32_t w[4]; bf16x8_t v; } pk;
-            pk.w[0] = pack2_t<DT>(p0[0], p0[1]); pk.w[1] = pack2_t<DT>(p0[2], p0[3]);
-            pk.w[2] = pack2_t<DT>(p1[0], p1[1]); pk.w[3] = pack2_t<DT>(p1[2], p1[3]);
-            const bf16x8_t pf = pk.v;
+            bf16x8_t pf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4_t p0 = ds[t][2 * kk], p1 = ds[t][2 * kk + 1];
+                union { uint32_t w[4]; bf16x8_t v; } pk;
+                pk.w[0] = pack2_t<DT>(p0[0], p0[1]); pk.w[1] = pack2_t<DT>(p0[2], p0[3]);
+                pk.w[2] = pack2_t<DT>(p1[0], p1[1]); pk.w[3] = pack2_t<DT>(p1[2], p1[3]);
+                pf[t] = pk.v;
+            }
             const int r0 = 32 * kk + 4 * g + tq;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int chunk = 2 * dt + (tp >> 1);
                 const bf16x4_t v0 = lds_tr16(sK + d_off(r0, chunk) + ((tp & 1) << 3));
                 const bf16x4_t v1 = lds_tr16(sK + d_off(r0 + 16, chunk) + ((tp & 1) << 3));
-                const bf16x8_t kf = (bf16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o[dt] = mfma16<DT>(kf, pf, o[dt]);
+                const bf16x8_t kT = (bf16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[0][dt] = mfma16<DT>(kT, pf[0], o[0][dt]);
+                o[1][dt] = mfma16<DT>(kT, pf[1], o[1][dt]);
             }
         }
         // + dS[q, x] k_x: lane (fr, g) holds columns dt*16 + 4g .. +3 of query fr
         {
-            const float dsx = colD[q];
+            const float dsx[2] = {colD[qa[0]], colD[qa[1]]};
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const uint2 m2 = *(const uint2*)(sK + d_off(XR, 2 * dt + (g >> 1)) + ((g & 1) << 3));
-                o[dt][0] = __builtin_fmaf(dsx, cvt16f_t<DT>((bf16_t)(m2.x & 0xffff)), o[dt][0]);
-                o[dt][1] = __builtin_fmaf(dsx, cvt16f_t<DT>((bf16_t)(m2.x >> 16)), o[dt][1]);
-                o[dt][2] = __builtin_fmaf(dsx, cvt16f_t<DT>((bf16_t)(m2.y & 0xffff)), o[dt][2]);
-                o[dt][3] = __builtin_fmaf(dsx, cvt16f_t<DT>((bf16_t)(m2.y >> 16)), o[dt][3]);
+                const float kx[4] = {cvt16f_t<DT>((bf16_t)(m2.x & 0xffff)), cvt16f_t<DT>((bf16_t)(m2.x >> 16)),
+                                     cvt16f_t<DT>((bf16_t)(m2.y & 0xffff)), cvt16f_t<DT>((bf16_t)(m2.y >> 16))};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[t][dt][e] = __builtin_fmaf(dsx[t], kx[e], o[t][dt][e]);
             }
         }
-        store_rows16<DT>(o, dqkv + ((size_t)s * L + q) * D3 + h * 64, true, g);
+        store_rows16<DT>(o[0], dqkv + ((size_t)s * L + qa[0]) * D3 + h * 64, true, g);
+        store_rows16<DT>(o[1], dqkv + ((size_t)s * L + qa[1]) * D3 + h * 64, true, g);
     }
 
-    // ------------------------------ pass B: dK, dV of rows 0..127 (a wave owns key tiles wave, wave + 4) ------------------------------
-#pragma unroll 1
-    for (int kt = wave; kt < ATX_NT; kt += 4) {
-        const int key = kt * 16 + fr;
-        bf16x8_t kf[2], vf[2];
+    // ------------------------------ pass B: dK, dV of rows 0..127 ------------------------------
+    // the wave's two key tiles (wave, wave + 4) walk the queries together: Q / dO fragments, lse / delta and the transposed
+    // dO / Q fragments are read once for both
+    {
+        const int ka[2] = {wave * 16 + fr, (wave + 4) * 16 + fr};
+        bf16x8_t kf[2][2], vf[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kf[ks] = *(const bf16x8_t*)(sK + d_off(key, (ks << 2) | g));
-            vf[ks] = *(const bf16x8_t*)(sV + d_off(key, (ks << 2) | g));
-        }
-        f32x4_t dk[4], dv[4];
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll 2      // (fully unrolled the two accumulator sets and four k-steps' fragments spill, as in the nine-tile kernel)
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[t][ks] = *(const bf16x8_t*)(sK + d_off(ka[t], (ks << 2) | g));
+                vf[t][ks] = *(const bf16x8_t*)(sV + d_off(ka[t], (ks << 2) | g));
+            }
+        f32x4_t dk[2][4], dv[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dk[t][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                dv[t][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll 2      // (fully unrolled the four accumulator sets and four k-steps' fragments spill)
         for (int qq = 0; qq < ATX_NT / 2; ++qq) {  // query tiles (2qq, 2qq+1) = one 32-deep k-step
-            uint32_t pw[4], sw[4];
+            uint32_t pw[2][4], sw[2][4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * qq + half;
-                f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                bf16x8_t qf[2], gf[2];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8_t qf = *(const bf16x8_t*)(sQ + d_off(qt * 16 + fr, (ks << 2) | g));
-                    const bf16x8_t gf = *(const bf16x8_t*)(sG + d_off(qt * 16 + fr, (ks << 2) | g));
-                    a = mfma16<DT>(qf, kf[ks], a);  // S  [row q][col key]
-                    b = mfma16<DT>(gf, vf[ks], b);  // dP [row q][col key]
+                    qf[ks] = *(const bf16x8_t*)(sQ + d_off(qt * 16 + fr, (ks << 2) | g));
+                    gf[ks] = *(const bf16x8_t*)(sG + d_off(qt * 16 + fr, (ks << 2) | g));
                 }
                 const f32x4_t l4 = *(const f32x4_t*)(sLse + qt * 16 + 4 * g), d4 = *(const f32x4_t*)(sDel + qt * 16 + 4 * g);
-                float pv[4], dsv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -l4[e]));
-                    dsv[e] = pv[e] * __builtin_fmaf(b[e], scale, -d4[e]);
+                for (int t = 0; t < 2; ++t) {
+                    f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        a = mfma16<DT>(qf[ks], kf[t][ks], a);  // S  [row q][col key]
+                        b = mfma16<DT>(gf[ks], vf[t][ks], b);  // dP [row q][col key]
+                    }
+                    float pv[4], dsv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], c2, -l4[e]));
+                        dsv[e] = pv[e] * __builtin_fmaf(b[e], scale, -d4[e]);
+                    }
+                    pw[t][half * 2] = pack2_t<DT>(pv[0], pv[1]); pw[t][half * 2 + 1] = pack2_t<DT>(pv[2], pv[3]);
+                    sw[t][half * 2] = pack2_t<DT>(dsv[0], dsv[1]); sw[t][half * 2 + 1] = pack2_t<DT>(dsv[2], dsv[3]);
                 }
-                pw[half * 2] = pack2_t<DT>(pv[0], pv[1]); pw[half * 2 + 1] = pack2_t<DT>(pv[2], pv[3]);
-                sw[half * 2] = pack2_t<DT>(dsv[0], dsv[1]); sw[half * 2 + 1] = pack2_t<DT>(dsv[2], dsv[3]);
             }
-            union { uint32_t w[4]; bf16x8_t v; } pu, su;
+            bf16x8_t pf[2], sf[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { pu.w[e] = pw[e]; su.w[e] = sw[e]; }
-            const bf16x8_t pf = pu.v, sf = su.v;
+            for (int t = 0; t < 2; ++t) {
+                union { uint32_t w[4]; bf16x8_t v; } pu, su;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pu.w[e] = pw[t][e]; su.w[e] = sw[t][e]; }
+                pf[t] = pu.v; sf[t] = su.v;
+            }
+            // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
             const int r0 = 32 * qq + 4 * g + tq;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -746,30 +786,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
                 const bf16x4_t q1 = lds_tr16(sQ + d_off(r0 + 16, chunk) + ((tp & 1) << 3));
                 const bf16x8_t gT = (bf16x8_t){g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
                 const bf16x8_t qT = (bf16x8_t){q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-                dv[dt] = mfma16<DT>(gT, pf, dv[dt]);
-                dk[dt] = mfma16<DT>(qT, sf, dk[dt]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    dv[t][dt] = mfma16<DT>(gT, pf[t], dv[t][dt]);
+                    dk[t][dt] = mfma16<DT>(qT, sf[t], dk[t][dt]);
+                }
             }
         }
         // + dS[x, key] q_x and P[x, key] dO_x: lane (fr, g) holds columns dt*16 + 4g .. +3 of key fr
         {
-            const float rds = rowD[key], rp = rowS[key];
+            const float rds[2] = {rowD[ka[0]], rowD[ka[1]]}, rp[2] = {rowS[ka[0]], rowS[ka[1]]};
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int off = d_off(XR, 2 * dt + (g >> 1)) + ((g & 1) << 3);
                 const uint2 q2 = *(const uint2*)(sQ + off), g2 = *(const uint2*)(sG + off);
-                dk[dt][0] = __builtin_fmaf(rds, cvt16f_t<DT>((bf16_t)(q2.x & 0xffff)), dk[dt][0]);
-                dk[dt][1] = __builtin_fmaf(rds, cvt16f_t<DT>((bf16_t)(q2.x >> 16)), dk[dt][1]);
-                dk[dt][2] = __builtin_fmaf(rds, cvt16f_t<DT>((bf16_t)(q2.y & 0xffff)), dk[dt][2]);
-                dk[dt][3] = __builtin_fmaf(rds, cvt16f_t<DT>((bf16_t)(q2.y >> 16)), dk[dt][3]);
-                dv[dt][0] = __builtin_fmaf(rp, cvt16f_t<DT>((bf16_t)(g2.x & 0xffff)), dv[dt][0]);
-                dv[dt][1] = __builtin_fmaf(rp, cvt16f_t<DT>((bf16_t)(g2.x >> 16)), dv[dt][1]);
-                dv[dt][2] = __builtin_fmaf(rp, cvt16f_t<DT>((bf16_t)(g2.y & 0xffff)), dv[dt][2]);
-                dv[dt][3] = __builtin_fmaf(rp, cvt16f_t<DT>((bf16_t)(g2.y >> 16)), dv[dt][3]);
+                const float qx[4] = {cvt16f_t<DT>((bf16_t)(q2.x & 0xffff)), cvt16f_t<DT>((bf16_t)(q2.x >> 16)),
+                                     cvt16f_t<DT>((bf16_t)(q2.y & 0xffff)), cvt16f_t<DT>((bf16_t)(q2.y >> 16))};
+                const float gx[4] = {cvt16f_t<DT>((bf16_t)(g2.x & 0xffff)), cvt16f_t<DT>((bf16_t)(g2.x >> 16)),
+                                     cvt16f_t<DT>((bf16_t)(g2.y & 0xffff)), cvt16f_t<DT>((bf16_t)(g2.y >> 16))};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dk[t][dt][e] = __builtin_fmaf(rds[t], qx[e], dk[t][dt][e]);
+                        dv[t][dt][e] = __builtin_fmaf(rp[t], gx[e], dv[t][dt][e]);
+                    }
             }
         }
-        bf16_t* krow = dqkv + ((size_t)s * L + key) * D3 + Dm + h * 64;
-        store_rows16<DT>(dk, krow, true, g);
-        store_rows16<DT>(dv, krow + Dm, true, g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16_t* krow = dqkv + ((size_t)s * L + ka[t]) * D3 + Dm + h * 64;
+            store_rows16<DT>(dk[t], krow, true, g);
+            store_rows16<DT>(dv[t], krow + Dm, true, g);
+        }
     }
 }
 
