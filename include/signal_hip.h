@@ -109,10 +109,18 @@ int sig_gemm_tn_grouped(const SigTnJobDesc* jobs, int n, int Mr, int dtype, void
  * y_bf16 / y_f32 / mean / rstd may be NULL when not wanted. */
 int sig_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y_bf16, float* y_f32,
                       float* mean, float* rstd, int M, int D, float eps, int dtype, void* stream);
-/* dx = dres + LN'(dy); dgamma/dbeta are ACCUMULATED (atomics) and may both be NULL. */
+/* dx = dres + LN'(dy); dgamma/dbeta are ACCUMULATED and may both be NULL. */
 int sig_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                       const float* rstd, const float* dres, float* dx_f32, uint16_t* dx_bf16, float* dgamma,
                       float* dbeta, int M, int D, int dtype, void* stream);
+/* Chained column reduce for a caller that owns a whole backward pass (the stage calls below run LayerNorm backward 25 times per
+ * step): with sig_tune_ln_defer(1) a LayerNorm backward that produces column sums (dgamma / dbeta, the bias gradients that ride
+ * along in sig_block_bwd) leaves its per-workgroup partial rows in library scratch and the NEXT LayerNorm backward on the same
+ * stream adds them up in its first workgroups, instead of one small reduce launch each; sig_ln_flush(stream) launches the reduce
+ * for whatever is still pending.  Until the flush the affected gradients are incomplete.  Returns the previous setting.  Same
+ * summation order either way (bit-identical gradients). */
+int sig_tune_ln_defer(int on);
+int sig_ln_flush(void* stream);
 
 /* Self-attention of nn.MultiheadAttention as called at modeling/clip/model.py:223-225 (no mask, no dropout):
  * qkv bf16 [S*L, 3*H*64] packed (q|k|v, head h = columns 64h..64h+63 of each) -> out bf16 [S*L, H*64],

@@ -28,6 +28,8 @@ int sig_version(void) { return SIG_ABI_VERSION; }
 int sig_prof_begin(int epilogue, int N, int K, int max_launches) { return sig_prof_begin_impl(epilogue, N, K, max_launches); }
 int sig_tune_gemm_tile(int tile) { return sig_tune_gemm_tile_impl(tile); }
 int sig_tune_nt_persist(int on) { return sig_tune_nt_persist_impl(on); }
+int sig_tune_ln_defer(int on) { return sig_tune_ln_defer_impl(on); }
+int sig_ln_flush(void* stream) { return sig_ln_flush_impl((hipStream_t)stream); }
 int sig_tune_reserved_cus(int n) { return sig_tune_reserved_cus_impl(n); }
 int sig_tune_tn_path(int path) { return sig_tune_tn_path_impl(path); }
 int sig_debug_tn_plan(int tiles, int ks, int grid, int cs_units, int* out8) { return sig_debug_tn_plan_impl(tiles, ks, grid, cs_units, out8); }

@@ -76,6 +76,38 @@ int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* be
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (register partials per wave, LDS across the 4 waves,
 // one atomic per column per workgroup).
 // ------------------------------------------------------------------------------------------------
+// One pending column reduce: out_k[c] += sum over blocks b of part[b][k][c], k = 0 (dgamma), 1 (dbeta), 2 (dx column sums)
+struct LnPrevReduce {
+    const float* part;       // [nblocks][3][D] partial rows of the previous launch (nullptr: nothing pending)
+    float* out[3];
+    int nblocks, D, groups;  // groups = 3 * ceil(D / 64): one (array k, 64-column slice) per workgroup
+};
+// a workgroup of 64 * WPB threads adds up one (k, 64-column) group: the 16 row chunks of ln_bwd_reduce_kernel, two per wave,
+// combined through LDS in chunk order.  `sm` = at least 16 * 64 floats of the caller's LDS, free before its own rows start.
+template <int WPB>
+__device__ __forceinline__ void ln_reduce_group(const LnPrevReduce& pv, int group, float* sm) {
+    const int slices = (pv.D + 63) >> 6, k = group / slices, c = (group - k * slices) * 64 + (threadIdx.x & 63);
+    float* out = pv.out[k];
+    if (out != nullptr) {           // (uniform)
+        const int per = (pv.nblocks + 15) >> 4;
+        for (int chunk = threadIdx.x >> 6; chunk < 16; chunk += WPB) {
+            const int b0 = chunk * per, b1 = b0 + per < pv.nblocks ? b0 + per : pv.nblocks;
+            float acc = 0.f;
+            if (c < pv.D)
+                for (int b = b0; b < b1; ++b) acc += pv.part[((size_t)b * 3 + k) * pv.D + c];
+            sm[chunk * 64 + (threadIdx.x & 63)] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64 && c < pv.D) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += sm[q * 64 + threadIdx.x];
+            out[c] += t;
+        }
+        __syncthreads();
+    }
+}
+
 #ifndef LN_BWD_WPB
 #define LN_BWD_WPB 8    // waves per block of layernorm_bwd_kernel (8 x 384 blocks: half the partial rows of 4 x 768 for the same waves)
 #endif
@@ -85,7 +117,7 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dxf, bf16_t* __restrict__ dxb,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D,
-                                                            float* __restrict__ dxsum, int dt, float* __restrict__ part) {
+                                                            float* __restrict__ dxsum, int dt, float* __restrict__ part, LnPrevReduce prev) {
     // NV = float4 per lane (D <= 256*NV): sized to the row so the per-lane accumulators stay small (more waves per SIMD).
     // Column sums (dgamma, dbeta, optional sum of dx): every wave parks its accumulators in its own LDS slice (plain
     // b128 stores), the block adds the slices and issues one global atomic per column.  That flush runs at the
@@ -96,6 +128,10 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
     __shared__ float red[SUMX ? 3 : 2][WPB][256 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool sums = dgamma != nullptr || SUMX;
+    // Chained column reduce (sig_tune_ln_defer): the PREVIOUS LayerNorm backward on this stream left its per-block partial rows in
+    // scratch instead of paying a launch for ln_bwd_reduce_kernel; the first blocks of this launch add them up before their own
+    // rows -- the same sixteen row chunks in the same order as that kernel, so the sums carry the same bits.
+    if (prev.part != nullptr && (int)blockIdx.x < prev.groups) ln_reduce_group<WPB>(prev, blockIdx.x, &red[0][0][0]);
     float4 ag[NV], ab[NV], ax[SUMX ? NV : 1], gm[NV];
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
@@ -221,14 +257,52 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
 template <bool DY_BF16, int NV>
 static void launch_ln_bwd(int blocks, hipStream_t st, const void* dy, const float* x, const float* gamma, const float* mean,
                           const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma, float* dbeta, int M,
-                          int D, float* dx_colsum, int dt, float* part) {
+                          int D, float* dx_colsum, int dt, float* part, const LnPrevReduce& prev) {
     constexpr int WPB = LN_BWD_WPB;
     if (dx_colsum)
         hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, true, WPB>), dim3(blocks), dim3(64 * WPB), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part);
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part, prev);
     else
         hipLaunchKernelGGL((layernorm_bwd_kernel<DY_BF16, NV, false, WPB>), dim3(blocks), dim3(64 * WPB), 0, st, dy, x, gamma, mean, rstd, dres,
-                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part);
+                           dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part, prev);
+}
+
+// ---- chained column reduce: state per (device, stream) ----------------------------------------------------------------------
+// sig_tune_ln_defer(1): a LayerNorm backward that produces column sums no longer launches ln_bwd_reduce_kernel behind itself; it
+// leaves a record here and the NEXT LayerNorm backward on the same stream adds the rows up in its first workgroups (28 launches of
+// ~7 us + their boundaries per train step otherwise).  sig_ln_flush(stream) launches the reduce for whatever is still pending.
+// Until then the affected dgamma / dbeta / column sums are incomplete: the mode is for a caller that owns the whole backward (the
+// training engine turns it on around vit_backward and flushes before anybody reads the gradients; with a data-parallel reducer
+// hooked in it stays off, because a block's bucket is sent as soon as that block's backward is enqueued).
+#include <atomic>
+#include <mutex>
+static std::atomic<int> g_ln_defer{0};
+struct LnPending { int dev; hipStream_t st; LnPrevReduce job; int slot; };
+static LnPending g_ln_pending[8];
+static int g_ln_npending = 0;
+static std::mutex g_ln_mu;
+int sig_tune_ln_defer_impl(int on) {
+    const int prev = g_ln_defer.exchange(on != 0);
+    return prev;
+}
+static LnPending* ln_pending_for(hipStream_t st, bool create) {      // (g_ln_mu held)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < g_ln_npending; ++i)
+        if (g_ln_pending[i].st == st && g_ln_pending[i].dev == dev) return &g_ln_pending[i];
+    if (!create || g_ln_npending == 8) return nullptr;
+    g_ln_pending[g_ln_npending] = LnPending{dev, st, LnPrevReduce{nullptr, {nullptr, nullptr, nullptr}, 0, 0, 0}, 1};
+    return &g_ln_pending[g_ln_npending++];
+}
+int sig_ln_flush_impl(hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_ln_mu);
+    LnPending* pd = ln_pending_for(st, false);
+    if (pd == nullptr || pd->job.part == nullptr) return 0;
+    const LnPrevReduce j = pd->job;
+    pd->job.part = nullptr;
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(sig_ceil_div(j.D, 64), 3), dim3(1024), 0, st, j.part, j.nblocks, j.D, j.out[0], j.out[1], j.out[2]);
+    SIG_CHECK_LAUNCH("layernorm_bwd_reduce (flush)");
+    return 0;
 }
 
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
@@ -250,8 +324,29 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     int blocks = sig_ceil_div(M, LN_BWD_WPB * (k > 0 ? k : 1));
     const int nv = (D + 255) / 256;
     const bool sums = dgamma != nullptr || dx_colsum != nullptr;
-    float* part = (sums && use_part && blocks > 16) ? sig_stream_scratch(st, (size_t)blocks * 3 * D * sizeof(float), 1) : nullptr;
-#define SIG_LN(BF, NV_) launch_ln_bwd<BF, NV_>(blocks, st, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part)
+    // chained mode: this launch adds up the previous launch's partial rows (if any) and writes its own to the OTHER scratch slot
+    LnPrevReduce prev{nullptr, {nullptr, nullptr, nullptr}, 0, 0, 0};
+    LnPending* pd = nullptr;
+    int slot = 1;
+    const bool defer = g_ln_defer.load() != 0;
+    std::unique_lock<std::mutex> lock(g_ln_mu, std::defer_lock);
+    if (defer) {
+        lock.lock();
+        pd = ln_pending_for(st, true);
+        if (pd != nullptr) {
+            if (pd->job.part != nullptr && pd->job.groups <= blocks) { prev = pd->job; pd->job.part = nullptr; }
+            slot = pd->slot == 1 ? 3 : 1;
+        }
+    }
+    float* part = (sums && use_part && blocks > 16) ? sig_stream_scratch(st, (size_t)blocks * 3 * D * sizeof(float), slot) : nullptr;
+    if (prev.part != nullptr && sums && part == nullptr) {
+        // this launch adds its own column sums with atomics (few blocks, or no scratch): a chained reduce inside it could meet
+        // them on the same addresses -- pay the previous launch's reduce as its own launch, first
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(sig_ceil_div(prev.D, 64), 3), dim3(1024), 0, st, prev.part, prev.nblocks, prev.D, prev.out[0],
+                           prev.out[1], prev.out[2]);
+        prev.part = nullptr;
+    }
+#define SIG_LN(BF, NV_) launch_ln_bwd<BF, NV_>(blocks, st, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, dgamma, dbeta, M, D, dx_colsum, dt, part, prev)
     if (dy_is_bf16) {
         if (nv == 1) SIG_LN(true, 1); else if (nv == 2) SIG_LN(true, 2); else if (nv == 3) SIG_LN(true, 3); else SIG_LN(true, 4);
     } else {
@@ -260,8 +355,13 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
 #undef SIG_LN
     SIG_CHECK_LAUNCH("layernorm_bwd");
     if (part) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(sig_ceil_div(D, 64), 3), dim3(1024), 0, st, part, blocks, D, dgamma, dbeta, dx_colsum);
-        SIG_CHECK_LAUNCH("layernorm_bwd_reduce");
+        if (pd != nullptr && pd->job.part == nullptr) {      // leave the rows for the next launch on this stream (or sig_ln_flush)
+            pd->job = LnPrevReduce{part, {dgamma, dbeta, dx_colsum}, blocks, D, 3 * sig_ceil_div(D, 64)};
+            pd->slot = slot;
+        } else {
+            hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(sig_ceil_div(D, 64), 3), dim3(1024), 0, st, part, blocks, D, dgamma, dbeta, dx_colsum);
+            SIG_CHECK_LAUNCH("layernorm_bwd_reduce");
+        }
     }
     return 0;
 }

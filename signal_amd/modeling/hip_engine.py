@@ -428,6 +428,20 @@ class HipPath:
         """ws["dtokens"] (the gradient of the token tensor, accumulated by the consumers) -> accumulates every ViT parameter
         gradient into flat.grad."""
         st, d = _stream(), ref(ws["dims"])
+        # The 25 LayerNorm backwards of this pass chain their column reduces (each launch adds up the previous one's partial rows
+        # in its first workgroups; one flush at the end) instead of 25 small reduce launches -- unless a data-parallel reducer is
+        # hooked in: it sends a block's bucket as soon as that block's backward is enqueued, so every gradient must be final then.
+        lib = _lib.load()
+        chain = self.on_block_grads_ready is None and self.on_head_grads_ready is None and hasattr(lib, "sig_tune_ln_defer")
+        prev_defer = lib.sig_tune_ln_defer(1) if chain else 0
+        try:
+            self._vit_backward_stages(ws, st, d)
+        finally:
+            if chain:
+                lib.sig_tune_ln_defer(prev_defer)
+                _lib.call("sig_ln_flush", st)
+
+    def _vit_backward_stages(self, ws, st, d):
         _lib.call("sig_head_bwd", d, ref(self.head_p), ref(ws["head_a"]), ref(self.head_g), ws["dtokens"].data_ptr(),
                   ws["dtok_b"].data_ptr(), ws["dh"].data_ptr(), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(),
                   self.b_proj_grad[self.layers - 1].data_ptr(), st)

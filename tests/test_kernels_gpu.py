@@ -286,6 +286,44 @@ def test_layernorm(dev, dt16, m, d):
         assert rel_err(db, br.grad) < max(tol, 2e-5)
 
 
+def test_layernorm_bwd_chained_column_reduce(dev):
+    """sig_tune_ln_defer: consecutive LayerNorm backwards on one stream chain their column reduces (each launch adds up the previous
+    launch's partial rows in its first workgroups; sig_ln_flush pays the last one) -- the gradients must carry the same bits as
+    with one reduce launch per call, the dx outputs are untouched by the mode, and nothing is left pending after the flush."""
+    from signal_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(21)
+    m, d = 24768, 768
+    xs = [torch.randn(m, d, generator=g).to(dev) for _ in range(3)]
+    dys = [torch.randn(m, d, generator=g).bfloat16().to(dev) for _ in range(3)]
+    gam = [(1 + 0.1 * torch.randn(d, generator=g)).to(dev) for _ in range(3)]
+    mean = [x.mean(1) for x in xs]
+    rstd = [(x.var(1, unbiased=False) + 1e-5).rsqrt() for x in xs]
+
+    def run(defer):
+        outs = []
+        prev = lib.sig_tune_ln_defer(1 if defer else 0)
+        try:
+            for i in range(3):
+                dxf = torch.zeros(m, d, device=dev)
+                dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+                ops.layernorm_bwd(dys[i], xs[i], gam[i], mean[i], rstd[i], m, dx_f32=dxf, dgamma=dg, dbeta=db)
+                outs.append((dxf, dg, db))
+        finally:
+            lib.sig_tune_ln_defer(prev)
+            _lib.call("sig_ln_flush", torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = run(False), run(True)
+    for (dxa, dga, dba), (dxb, dgb, dbb) in zip(a, b):
+        assert torch.equal(dxa, dxb)
+        assert torch.equal(dga, dgb) and torch.equal(dba, dbb), "chained and per-call reduces must add in the same order"
+    ref = (dys[1].float() * ((xs[1] - mean[1][:, None]) * rstd[1][:, None])).sum(0)
+    assert rel_err(b[1][1], ref) < 2e-5
+
+
 def _attn_ref(qkv, s, l, h):
     d = h * 64
     q, k, v = qkv.float().reshape(s, l, 3, h, 64).permute(2, 0, 3, 1, 4)
