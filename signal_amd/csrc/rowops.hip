@@ -86,6 +86,7 @@ struct LnPrevReduce {
 // combined through LDS in chunk order.  `sm` = at least 16 * 64 floats of the caller's LDS, free before its own rows start.
 template <int WPB>
 __device__ __forceinline__ void ln_reduce_group(const LnPrevReduce& pv, int group, float* sm) {
+#pragma clang fp reassociate(off)       // the ORDER of these additions is the contract (bit-identical to ln_bwd_reduce_kernel); -ffast-math would re-tree them
     const int slices = (pv.D + 63) >> 6, k = group / slices, c = (group - k * slices) * 64 + (threadIdx.x & 63);
     float* out = pv.out[k];
     if (out != nullptr) {           // (uniform)
@@ -93,8 +94,20 @@ __device__ __forceinline__ void ln_reduce_group(const LnPrevReduce& pv, int grou
         for (int chunk = threadIdx.x >> 6; chunk < 16; chunk += WPB) {
             const int b0 = chunk * per, b1 = b0 + per < pv.nblocks ? b0 + per : pv.nblocks;
             float acc = 0.f;
-            if (c < pv.D)
-                for (int b = b0; b < b1; ++b) acc += pv.part[((size_t)b * 3 + k) * pv.D + c];
+            if (c < pv.D) {
+                // every row of the chunk requested before any is added (same order of addition as ln_bwd_reduce_kernel: row by
+                // row); with one load in flight per thread the 2 x 28 rows of a wave were 13 us of latency on the critical path
+                const float* src = pv.part + (size_t)k * pv.D + c;
+                const size_t rs = (size_t)3 * pv.D;
+                for (int b = b0; b < b1; b += 32) {      // (a chunk is at most 32 rows at the 512-block cap: one batch)
+                    float v[32];
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) v[q] = b + q < b1 ? src[(size_t)(b + q) * rs] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 32; ++q)
+                        if (b + q < b1) acc += v[q];
+                }
+            }
             sm[chunk * 64 + (threadIdx.x & 63)] = acc;
         }
         __syncthreads();
@@ -131,7 +144,10 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
     // Chained column reduce (sig_tune_ln_defer): the PREVIOUS LayerNorm backward on this stream left its per-block partial rows in
     // scratch instead of paying a launch for ln_bwd_reduce_kernel; the first blocks of this launch add them up before their own
     // rows -- the same sixteen row chunks in the same order as that kernel, so the sums carry the same bits.
-    if (prev.part != nullptr && (int)blockIdx.x < prev.groups) ln_reduce_group<WPB>(prev, blockIdx.x, &red[0][0][0]);
+    // The launcher makes the grid a little larger than the exact fit in this mode, so the LAST workgroups walk one row per wave
+    // fewer than the first ones: the reduce rides in their slack instead of on the launch's critical path.
+    if (prev.part != nullptr && (int)blockIdx.x >= (int)gridDim.x - prev.groups)
+        ln_reduce_group<WPB>(prev, (int)blockIdx.x - ((int)gridDim.x - prev.groups), &red[0][0][0]);
     float4 ag[NV], ab[NV], ax[SUMX ? NV : 1], gm[NV];
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(64 * WPB) void layernorm_bwd_kernel(const void* __r
 // columns of one array; 16 row chunks are summed in parallel and combined through LDS in chunk order (deterministic)
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int D, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ dxsum) {
+#pragma clang fp reassociate(off)       // fixed order of addition: see ln_reduce_group
     __shared__ float sm[16][64];
     const int k = blockIdx.y;
     float* out = k == 0 ? dgamma : (k == 1 ? dbeta : dxsum);
@@ -329,6 +346,14 @@ int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, con
     LnPending* pd = nullptr;
     int slot = 1;
     const bool defer = g_ln_defer.load() != 0;
+    if (blocks > 64) {
+        // room for the chained reduce: up to 40 more workgroups while the rows per wave of the busiest one stay the same and the
+        // grid stays one round (cap) -- then the last workgroups have a row per wave less than the first ones.  (In both modes:
+        // the partial rows, and with them the bits of the column sums, depend on the grid.)
+        int more = blocks + 40 < cap ? blocks + 40 : cap;
+        while (more > blocks && sig_ceil_div(M, LN_BWD_WPB * more) != sig_ceil_div(M, LN_BWD_WPB * blocks)) --more;
+        blocks = more;
+    }
     std::unique_lock<std::mutex> lock(g_ln_mu, std::defer_lock);
     if (defer) {
         lock.lock();
