@@ -30,6 +30,22 @@
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
+#ifdef SIG_GEMM_STAMPS   // diagnostic build only (tools/persist_stamps.py): where does a workgroup's time go?
+// per workgroup: [0] start, [1] first stage landed, then per tile t < 7: [2 + 2t] last K-step done, [3 + 2t] conversion done; [16] end
+__device__ unsigned long long g_pstamps[256 * 17];
+extern "C" int sig_debug_read_pstamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 256 * 17) == hipSuccess ? 0 : 2;
+}
+#define PP_STAMP(slot)                                                                                        \
+    do {                                                                                                      \
+        unsigned long long v_;                                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory");                            \
+        if (tid == 0 && blockIdx.x < 256 && (slot) < 17) g_pstamps[blockIdx.x * 17 + (slot)] = v_;              \
+    } while (0)
+#else
+#define PP_STAMP(slot)
+#endif
+
 #define PP_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define PP_WAIT3(n, a) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]))
 #define PP_WAIT7(n, a, b) \
@@ -51,6 +67,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = p.K >> 6;
+    PP_STAMP(0);
 
     // ---- this workgroup's tiles: XCD x owns a contiguous range of the band-major tile order, its workgroups take
     //      consecutive tiles of it round by round (what an XCD's L2 sees per round is 32 neighbouring tiles)
@@ -236,6 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
     for (int j = 0; j < 4; ++j) dma_b(j, bcur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    PP_STAMP(1);
     rd_a(0, 0, H0{}, aX);
     rd_b(0, 0, bX);
 #pragma unroll
@@ -284,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
             const bf16_t* asrc = a_in ? acur + (kt + 2) * 64 : anext + (kt + 2 - nk) * 64;
             step(std::integral_constant<int, -1>{}, kt & 1, bsrc, b_in || has_next, asrc, a_in || has_next);
         }
+        PP_STAMP(2 + 2 * t);
         // ---- the tile is complete: finish it in registers and park it (every unit of the previous tile left in K-steps 0..8)
         const char* tout = (const char*)p.out + ((size_t)m0 * p.ldo + n0) * 2;
         f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
@@ -347,6 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
                 }
             }
         }
+        PP_STAMP(3 + 2 * t);
         pout = tout;
         m0 = m1; n0 = n1;
         acur = anext; bcur = bnext;
@@ -360,6 +380,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
         asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(hbase), "n"((u - 12) * 512) : "memory");
         pp_store8(unit_base(pout, u), lane_out, v);
     }
+#ifdef SIG_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_STAMP(16);
+#endif
 }
 
 // eligibility and launch -----------------------------------------------------------------------------------------------
