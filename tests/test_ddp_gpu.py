@@ -186,7 +186,7 @@ def run(force):
     first = (float(loss), model.hip.flat.grad.clone(), model.hip.flat.data.clone())
     loss2 = ts.step(*batch)
     torch.cuda.synchronize()
-    assert torch.isfinite(loss2) and abs(float(loss2) - first[0]) < 0.2 * abs(first[0]), (first[0], float(loss2))
+    assert torch.isfinite(loss2) and float(loss2) < 1.5 * abs(first[0]), (first[0], float(loss2))   # (one Adam step at 3.5e-4 moves it 4.15 -> 2.6)
     return first[0], first[1], first[2], sent, ts
 l0, g0, p0, _, _ = run(False)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1, device_id=dev)
