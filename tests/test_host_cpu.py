@@ -461,3 +461,22 @@ def test_grouped_wgrad_work_plan_covers_every_unit_once():
     # the benched shape: 2 long chunks of 176 K-steps + a short one of 36 taken 4 tiles per workgroup, 243 + 13 workgroups
     _lib.call("sig_debug_tn_plan", 108, 388, 256, 36, ctypes.cast(out, ctypes.c_void_p))
     assert list(out) == [1, 3, 176, 4, 216, 27, 256, 1], list(out)
+
+
+def test_bench_traffic_guard_tracks_the_planner():
+    """bench.py's `roofline.traffic` is a committed PMC figure; `traffic_stale` must say when the library no longer plans the
+    roofline kernel the way it was profiled.  No GPU: the planner is host code.  (1) for the bench workload (B = 64: 24768 rows,
+    256 CUs) the library's plan IS the one recorded in profiles/r04_traffic.json, so the committed figure is current for the
+    shipped code; (2) a different plan, or a kernel that was never profiled, is reported as stale / absent."""
+    import importlib, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = importlib.import_module("bench")
+    ent = json.load(open(os.path.join(root, "profiles", "r04_traffic.json")))["kernels"]["gemm_tn_group_kernel"]
+    live = bench.live_tn_plan(3 * 64 * 129)
+    assert live == list(ent["plan"]), (live, ent["plan"])
+    t = bench.committed_traffic("gemm_tn_group_kernel", 2.0 * ent["avg_us_rocprofv3"], live)      # another box's clock: not stale
+    assert t["traffic_stale"] is False and t["traffic"] == ent["bytes_per_launch"] and "r04_traffic.json" in t["traffic_source"]
+    other = list(live); other[2] += 8                                                              # longer row chunks
+    assert bench.committed_traffic("gemm_tn_group_kernel", ent["avg_us_rocprofv3"], other)["traffic_stale"] is True
+    assert bench.live_tn_plan(3 * 32 * 129) != live                                                # (B = 32 plans differently)
+    assert bench.committed_traffic("no_such_kernel", 1.0, live)["traffic"] is None
