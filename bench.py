@@ -159,6 +159,20 @@ def cpu_baseline(workload, budget_s=20.0):
             "sample": f"{n} steps of B=8 synthetic 256x128 triplets (configs[0]), {what}, torch CPU {torch.get_num_threads()} threads"}
 
 
+def step_mfma_flops(B, train=True, L=129, D=768, depth=12, heads=12, patches=128):
+    """MFMA work of one step on one GPU, counted from the shapes: the 12 transformer blocks over the 3 streams (four linear
+    layers per block, attention's two products) and the patch embedding.  Training = forward + data gradients + weight
+    gradients (3x the forward GEMMs; the attention backward recomputes S and forms dP, dQ, dK, dV: 2.5x its forward).  The
+    SIM / GAM / LAM heads and the classifier (< 2 % of the step) are not counted."""
+    M = 3 * B * L
+    gemm = 2.0 * M * D * (3 * D + D + 4 * D + 4 * D)
+    attn = 4.0 * L * L * (D // heads) * heads * 3 * B
+    embed = 2.0 * (3 * B * patches) * D * D
+    if not train:
+        return depth * (gemm + attn) + embed
+    return depth * (3 * gemm + 3.5 * attn) + 2 * embed
+
+
 def live_tn_plan(M):
     """The grouped weight gradient's work plan for this run's shapes and free CUs, from the library's own planner
     (sig_debug_tn_plan): {balanced, nsplit, per, short_group, n_long, n_short_wg, workgroups, colsum_inside}."""
@@ -398,6 +412,13 @@ def main():
                      "launches": pn, "avg_us": round(pms / max(pn, 1) * 1e3, 2)},
         "parity": PARITY,
     }
+    # the whole step against the MFMA peak (per GPU): what the kernels above add up to, HBM-bound kernels, launch gaps and the
+    # optimizer included -- the figure the north star's ">= 40 % on the ViT block" is to be read against
+    sf = step_mfma_flops(B, train=args.workload == "train")
+    out["step_mfma"] = {"flops_per_step_per_gpu": sf, "achieved": round(sf / (el / args.steps) / 1e12, 1), "peak": PEAK_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(sf / (el / args.steps) / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                        "counts": "12 ViT-B/16 blocks x 3 streams + patch embedding, " + ("forward + dgrad + wgrad" if args.workload == "train" else "forward") +
+                                  "; fusion heads and classifier not counted"}
     if other is not None:
         out[other["dtype"]] = other
     if ddp_single is not None:

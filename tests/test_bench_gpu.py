@@ -42,6 +42,9 @@ def test_bench_default_is_the_train_step_with_the_json_contract():
     # library's planner for this run's shapes and CU count) with what the committed profile recorded
     assert r["traffic"] is None or (r["traffic"] > 1e8 and r["traffic_stale"] is False), r
     # the PCIe-inclusive rate is part of the default line (batches through DevicePrefetcher, as do_train feeds the engine)
+    sm = d["step_mfma"]          # whole step against the MFMA peak: shapes-derived flops / the same wall time as `value`
+    assert sm["unit"] == "TFLOP/s" and sm["peak"] == 2500.0 and abs(sm["flops_per_step_per_gpu"] / 13.092e12 - 1) < 1e-3
+    assert abs(sm["achieved"] - sm["flops_per_step_per_gpu"] / d["ms_per_step"] / 1e9) < 1.0 and 0.05 < sm["frac"] < r["frac"]
     hd = d["h2d_inclusive"]
     assert hd["unit"] == "triplets/s" and 0.7 * d["value"] < hd["value"] < 1.1 * d["value"], hd
     # the operand type that meets the north_star's 1e-3 has a driver-visible train figure of its own
