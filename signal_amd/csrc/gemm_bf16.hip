@@ -394,11 +394,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(SigGemmNT p) {
     // ---- staging: wave w moves A pieces w*PA.., B pieces w*4.. (8 rows x 128 B each) ----
     const bf16_t* ag[PA];
     const bf16_t* bg[4];
+    // rows of a last 160-row tile past the 128-row padding of the operand buffer read the last padded row instead (their
+    // accumulators are never stored: the epilogue predicates every access on row < M)
+    const int rlim = ((((p.M + 127) >> 7) << 7)) - 1;
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const int r = (wave * PA + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        ag[j] = p.A + (size_t)(m0 + r) * p.lda + c * 8;
+        const int row = BM == 128 ? m0 + r : min(m0 + r, rlim);
+        ag[j] = p.A + (size_t)row * p.lda + c * 8;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1056,7 +1060,7 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
         const int tm160 = (p.M + 159) / 160, t160 = tm160 * (p.N >> 7), t128 = (mp >> 7) * (p.N >> 7);
         const float c320 = (float)((t320 + cus - 1) / cus) * 81920.f / 0.83f;
         const float c256 = big ? (float)(((mp >> 8) * (p.N >> 8) + cus - 1) / cus) * 65536.f / 0.83f : 1e30f;
-        const float c160 = tm160 * 160 <= mp ? (float)((t160 + 2 * cus - 1) / (2 * cus)) * 40960.f / 0.68f : 1e30f;
+        const float c160 = (float)((t160 + 2 * cus - 1) / (2 * cus)) * 40960.f / 0.68f;
         const float c128 = (float)((t128 + 2 * cus - 1) / (2 * cus)) * 32768.f / 0.68f;
         // a tie with 256x256 (c_fc: 4 rounds x 1.25 = 5 rounds) goes to the kernel whose epilogue suits the outputs: with the
         // saved derivative as a second output the natural-orientation stores win (144 vs 153 us in the train step), with
@@ -1099,16 +1103,17 @@ static int launch_nt(const SigGemmNT& p_in, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)&gemm_nt_kernel<EPI, 160, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
             });
         p.band = choose_band(p.N >> 7, p.K, 128);
-        // 160-row tiles when they need fewer rounds of the chip's 512 slots per unit of work (1.25x a 128-row tile) and
-        // their last tile stays inside the 128-row padding of the operand buffers
+        // 160-row tiles when they need fewer rounds of the chip's 512 slots per unit of work (1.25x a 128-row tile); a last
+        // tile that passes the 128-row padding of the operand buffers re-reads the last padded row (B = 32: 12384 rows ->
+        // 78 x 6 = 468 tiles in one round for the N = 768 layers, against 582 of 128 rows in two)
         const int tn128 = p.N >> 7, t128 = (mp >> 7) * tn128, tm160 = (p.M + 159) / 160, t160 = tm160 * tn128;
         const int slots = 2 * cus;
         const float c128 = (float)((t128 + slots - 1) / slots), c160 = 1.25f * (float)((t160 + slots - 1) / slots);
-        bool tall = tm160 * 160 <= mp && c160 < c128;
+        bool tall = c160 < c128;
         static int force_bm = -1;
         if (force_bm < 0) { const char* e = getenv("SIG_GEMM_BM"); force_bm = e ? atoi(e) : 0; }
         if (force_bm == 128) tall = false;
-        if (force_bm == 160) tall = tm160 * 160 <= mp;
+        if (force_bm == 160) tall = true;
         if (tall) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 160, DT>), dim3(t160), dim3(256), 73728, st, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 128, DT>), dim3(t128), dim3(256), 65536, st, p);
     }

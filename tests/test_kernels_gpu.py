@@ -45,7 +45,7 @@ def padded(t, ops):
 # legal loop, the last row tile is partial: 24768 = 96 * 256 + 192 = 77 * 320 + 128); the nt_tile fixture pins each kernel
 # on every shape it is legal for
 GEMM_SHAPES = [(774, 384, 128), (1000, 768, 3072), (4128, 2304, 768), (129, 128, 64), (2000, 512, 192), (24768, 1536, 128),
-               (24768, 1536, 192)]
+               (24768, 1536, 192), (12384, 768, 768)]      # (the last: B = 32, whose last 160-row tile passes the 128-row padding)
 
 
 @pytest.fixture(params=[0, 128, 256, 320], ids=lambda t: f"tile{t}")
