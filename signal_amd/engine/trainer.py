@@ -84,6 +84,7 @@ class TrainStep:
             self.scaler = DeviceLossScaler(hip.flat.device)
         self.world = world_size
         self.reducer = None
+        self._one = None
         # CUs left to RCCL's channel workgroups while the gradient buckets are all-reduced under the backward pass: the
         # one-block-per-CU GEMMs are sized in rounds of the free CUs (include/signal_hip.h, sig_tune_reserved_cus)
         # Default 16 with an nccl (= RCCL) group, 0 otherwise; SIGNAL_RESERVED_CUS forces a value with any backend (the
@@ -139,7 +140,9 @@ class TrainStep:
             _lib.load().sig_tune_reserved_cus(self.reserved_cus)
         try:
             if self.scaler is None:
-                loss.backward()
+                if self._one is None or self._one.device != loss.device:
+                    self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+                loss.backward(gradient=self._one)          # (a cached 1: autograd would build one with a fill per step)
             else:
                 loss.backward(gradient=self.scaler.scale_tensor)
         finally:

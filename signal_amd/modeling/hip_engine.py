@@ -663,8 +663,9 @@ class SimFn(torch.autograd.Function):
         # of everything that consumed `out`; inference returns the workspace at once, so the caller gets a copy
         if not train:
             out = out.clone()
-        mask = ws["t"]["mask_f"].view(3, B, hip.L - 1).clone()
+        mask = ws["t"]["mask_f"].view(3, B, hip.L - 1).clone()      # (kept by the module as last_masks: the caller's own copy)
         ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)             # (no zero tensor built for the mask's "gradient")
         if not train:
             ctx.lease.release()
         return out, mask
@@ -672,6 +673,9 @@ class SimFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dmask):
         hip, ws = ctx.hip, ctx.ws
+        if dout is None:                             # nothing consumed the features: no gradient path through SIM this step
+            ctx.lease.release()
+            return (None,) * (3 + len(hip.sim_param_names))
         shared = ctx.acc is not None
         dtokens = ctx.acc if shared else torch.zeros(ctx.shape, dtype=F32, device=dout.device)
         if hip.direct_grads:
