@@ -266,7 +266,9 @@ def main():
             step()
         barrier()
         if prof:
-            _lib.call("sig_prof_begin", *prof, 64 * steps + 8)
+            # (events for every launch of the roofline kernel in the timed steps; past the library's cap of 65536 pairs -- about 1000
+            #  steps -- the later launches simply go untimed and the average is over the first ones)
+            _lib.call("sig_prof_begin", *prof, min(64 * steps + 8, 65536))
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
