@@ -45,9 +45,9 @@ int sig_prof_end(double* total_ms, int* launches, double* flops);
  * kernel is legal for the shape; returns the previous setting.  Same as the environment variable SIG_GEMM_TILE. */
 int sig_tune_gemm_tile(int tile);
 /* Tuning / test aid: the persistent 192x256 form of sig_gemm_nt (the store tail of tile n issued under the main loop of tile
- * n+1; wide K >= 768 contractions with a 16-bit output, whole 192-row tiles): 0 = off, 1 = the plain / bias epilogues (default),
- * 2 = also the QuickGELU forward without a saved derivative, wherever legal; returns the previous setting.  Environment
- * preset: SIG_NT_PERSIST. */
+ * n+1; wide K >= 768 contractions with a 16-bit output, whole 192-row tiles): 0 = off, 1 = the plain / bias epilogues and the
+ * GELU' dgrad (default), 2 = also the QuickGELU forward without a saved derivative, 3 = also with one (the training c_fc),
+ * wherever legal; returns the previous setting.  Environment preset: SIG_NT_PERSIST. */
 int sig_tune_nt_persist(int on);
 /* Same for the weight-gradient path: 128 = the 128x128-tile kernel with f32 atomics, one launch per weight; 256 = the 256x256
  * kernel, one launch per weight; 0 = default (a block's four weights grouped into one launch).  Environment: SIG_GEMM_TN_TILE. */

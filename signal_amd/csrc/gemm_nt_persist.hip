@@ -142,7 +142,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
     u32x2_t hr[12];
     const unsigned hbase = lds0 + HELD + wave * 6144 + lane * 8;
     const unsigned lane_out = (unsigned)((wm + 4 * g) * p.ldo + wn + 4 * fr) * 2u;       // byte offset inside a tile's output
-    const unsigned lane_aux = UMUL ? (unsigned)((wm + 4 * g) * p.ldaux + wn + 4 * fr) * 2u : 0u;
+    const unsigned lane_aux = (UMUL || GELU_FWD) ? (unsigned)((wm + 4 * g) * p.ldaux + wn + 4 * fr) * 2u : 0u;
+    const bool save_u = GELU_FWD && p.aux != nullptr;      // c_fc in training: QuickGELU'(pre-activation) is a second output
     const unsigned lane_bias = (unsigned)(wn + 4 * fr) * 4u;
     const size_t ldo2 = (size_t)p.ldo * 2, ldx2 = (size_t)p.ldaux * 2;
     const char* pout = nullptr;                                                            // previous tile's output base (uniform)
@@ -305,6 +306,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
         PP_STAMP(2 + 2 * t);
         // ---- the tile is complete: finish it in registers and park it (every unit of the previous tile left in K-steps 0..8)
         const char* tout = (const char*)p.out + ((size_t)m0 * p.ldo + n0) * 2;
+        // the second output of the training c_fc has no parking space left (24 units of y fill the registers and the LDS slots): its
+        // units are stored as they are produced, behind this tile's last DMA piece and ahead of the next tile's first -- K-step 0's
+        // boundary wait, which leaves only what was issued after ITS last piece in flight, covers them
+        const char* uout = save_u ? (const char*)p.aux + ((size_t)m0 * p.ldaux + n0) * 2 : nullptr;
         f32x4_t csum = {0.f, 0.f, 0.f, 0.f};
         // one store unit: rows i*16 + 4g + e, this lane's four columns; `w` = its aux values (GELU' dgrad only)
         auto finish_unit = [&](int i, int e, u32x2_t w) -> u32x2_t {
@@ -316,6 +321,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt192p_kernel(SigGemmNT p, int nt
                 tt += 1.0f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) sg[c] = __builtin_amdgcn_rcpf(tt[c]);
+                if (save_u) {
+                    const f32x4_t a = x * 1.702f;
+                    const f32x4_t d = sg + sg * (a - a * sg);          // s (1 + 1.702 u (1 - s)), as the per-tile epilogues save it
+                    pp_store8(uout + (size_t)(i * 16 + e) * ldx2, lane_aux, (u32x2_t){pack2_t<DT>(d[0], d[1]), pack2_t<DT>(d[2], d[3])});
+                }
                 x *= sg;
             }
             if constexpr (UMUL) {
@@ -411,8 +421,11 @@ bool sig_nt192p_eligible(const SigGemmNT& p, int epi, int cus) {
     // The QuickGELU forward has a persistent form too (sig_tune_nt_persist(2) admits it), but its ~2.9 k cycles of exp / rcp per
     // wave and tile sit between two tiles' MFMAs here where the per-tile kernels hide them under their store tail: measured
     // 119 -> 123 us for c_fc at inference (tools/persist_ab.py), so it stays with the 256x256 / 320x256 kernels.
+    // Level 3 adds the TRAINING c_fc (QuickGELU' as a second output, stored unit by unit between two tiles): 136-143 us against
+    // 134-136 for the 320-row kernel, so off as well (profiles/r04_experiments.md).
     const bool epi_ok = epi == SIG_EPI_BF16 || epi == SIG_EPI_BIAS_BF16 || epi == SIG_EPI_DGELU_BF16 ||
-                        (epi == SIG_EPI_BIAS_GELU_BF16 && p.aux == nullptr && persist_setting() >= 2);
+                        (epi == SIG_EPI_BIAS_GELU_BF16 && p.aux == nullptr && persist_setting() >= 2) ||
+                        (epi == SIG_EPI_BIAS_GELU_BF16 && p.aux != nullptr && !(p.ldaux & 3) && persist_setting() >= 3);
     if (!epi_ok || (p.colsum && epi != SIG_EPI_DGELU_BF16)) return false;
     const int nk = p.K >> 6;
     if ((p.N & 255) || (p.K & 63) || nk < 12 || (nk & 1)) return false;

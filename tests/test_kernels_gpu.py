@@ -145,8 +145,8 @@ def test_gemm_nt_persistent_kernel(dev, dt16, m, n, k):
     if k == 768:        # the GELU' dgrad (out = acc * aux, + column sums = the c_fc bias gradient): its plan is twelve K-steps long
         uu = torch.randn(m, n, generator=g).to(dt16).to(dev)
         want[ops.DGELU_BF16] = ref * uu.float()
-    got = {}
-    for persist in (2, 0):        # 2 = every epilogue that has a persistent form (1, the default, leaves the GELU forward out)
+    got, saved = {}, {}
+    for persist in (3, 0):        # 3 = every epilogue that has a persistent form (1, the default, leaves the GELU forward out)
         prev = lib.sig_tune_nt_persist(persist)
         try:
             for epi in want:
@@ -161,11 +161,20 @@ def test_gemm_nt_persistent_kernel(dev, dt16, m, n, k):
                     assert torch.equal(ob, ob2), "two launches of the persistent kernel differ"
                 assert not bool(ob[m:].abs().any()), "pad rows must stay untouched"
                 got[(persist, epi)] = ob
+            # the training form of c_fc: QuickGELU'(pre-activation) as a second output (stored unit by unit between two tiles)
+            ob, ub = (torch.zeros(ops.pad_rows(m), n, device=dev, dtype=dt16) for _ in range(2))
+            ops.gemm_nt(ap, w, m, ops.BIAS_GELU_BF16, ob, bias=bias, aux=ub)
+            assert not bool(ob[m:].abs().any()) and not bool(ub[m:].abs().any()), "pad rows must stay untouched"
+            saved[persist] = (ob, ub)
         finally:
             lib.sig_tune_nt_persist(prev)
     for epi, r in want.items():
-        assert rel_err(got[(2, epi)][:m].float(), r) < 4e-3 * T, epi
-        assert torch.equal(got[(2, epi)], got[(0, epi)]), f"persistent and per-tile kernels differ (epilogue {epi})"
+        assert rel_err(got[(3, epi)][:m].float(), r) < 4e-3 * T, epi
+        assert torch.equal(got[(3, epi)], got[(0, epi)]), f"persistent and per-tile kernels differ (epilogue {epi})"
+    sg = torch.sigmoid(1.702 * pre)
+    assert torch.equal(saved[3][0], got[(3, ops.BIAS_GELU_BF16)]) and torch.equal(saved[3][0], saved[0][0])
+    assert torch.equal(saved[3][1], saved[0][1]), "saved QuickGELU' differs between the persistent and the per-tile kernel"
+    assert rel_err(saved[3][1][:m].float(), sg * (1 + 1.702 * pre * (1 - sg))) < 4e-3 * T
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)

@@ -33,7 +33,7 @@ for rnd in range(3):
         bias = torch.randn(n, device=dev)
         out = torch.zeros(Mp, n, device=dev, dtype=dt)
         aux = (torch.randn(Mp, n, device=dev).to(dt) if aux_in else torch.zeros(Mp, n, device=dev, dtype=dt)) if has_aux else None
-        for persist in (0, 2):
+        for persist in (0, 3):
             prev = lib.sig_tune_nt_persist(persist)
             us = timeit(lambda: ops.gemm_nt(a, w, M, epi, out, bias=None if epi == ops.DGELU_BF16 else bias, aux=aux))
             lib.sig_tune_nt_persist(prev)
