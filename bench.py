@@ -299,8 +299,10 @@ def main():
             parallelism = parallelism.replace("RCCL", args.backend + " (test backend)")
         # dominant kernel of the train step by total time (profiles/r03_train_*): the grouped weight-gradient GEMM
         prof = (PROF_TN_GROUP, 0, 0)
-        kname = ("gemm_tn_group_kernel (one launch per transformer block: dW = dY^T X of in_proj, out_proj, c_fc, c_proj; "
-                 "M=%d rows, 108 tiles of 256x256)" % M)
+        # (the live bracket is the whole operation: the kernel AND its tn_group_reduce_kernel, so `achieved` is the operation-level
+        #  rate; the rocprofv3 average in `traffic_profile_avg_us` is the kernel alone, + ~28 us of reduce per block)
+        kname = ("gemm_tn_group_kernel + tn_group_reduce_kernel (one pair per transformer block: dW = dY^T X of in_proj, out_proj, c_fc, "
+                 "c_proj; M=%d rows, 108 tiles of 256x256; live bracket = kernel + reduce)" % M)
         kkey = "gemm_tn_group_kernel"
     else:
         step = fwd_step
