@@ -49,6 +49,10 @@ int sig_tune_gemm_tile(int tile);
  * GELU' dgrad (default), 2 = also the QuickGELU forward without a saved derivative, 3 = also with one (the training c_fc),
  * wherever legal; returns the previous setting.  Environment preset: SIG_NT_PERSIST. */
 int sig_tune_nt_persist(int on);
+/* Tuning / test aid: waves per workgroup of the attention backward at L = 129 (16 * 8 + 1, every shipped geometry): 8 = one
+ * 16-row tile per wave and pass (default; two resident workgroups put four waves on a SIMD), 4 = two tiles per wave sharing their
+ * fragment reads.  Bit-identical results; returns the previous setting.  Environment preset: SIG_ATTN_BWD_WAVES. */
+int sig_tune_attn_bwd_waves(int waves);
 /* Same for the weight-gradient path: 128 = the 128x128-tile kernel with f32 atomics, one launch per weight; 256 = the 256x256
  * kernel, one launch per weight; 0 = default (a block's four weights grouped into one launch).  Environment: SIG_GEMM_TN_TILE. */
 int sig_tune_tn_path(int path);

@@ -9,6 +9,7 @@
 // groups that share a query.
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "sig_common.h"
@@ -493,11 +494,16 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
 // Everything else (dual-use LDS images, passes A and B, in-register dS) is the kernel above with 8 tiles.
 // ------------------------------------------------------------------------------------------------
 #define ATX_NT 8
-template <int DT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+#ifndef SIG_ATTN_BWD_WAVES8_DEFAULT
+#define SIG_ATTN_BWD_WAVES8_DEFAULT 1
+#endif
+// PAIR = tiles per wave and pass: 2 = four waves (256 threads), 1 = eight waves (512 threads, <= 128 registers): two resident
+// blocks then put FOUR waves on a SIMD, two of them in the arithmetic phase while the other block stages
+template <int DT, int PAIR>
+__global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dqkv, int S, int H) {
-    constexpr int L = 16 * ATX_NT + 1, XR = 16 * ATX_NT;
+    constexpr int L = 16 * ATX_NT + 1, XR = 16 * ATX_NT, NW = ATX_NT / PAIR, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem;
     char* sK = smem + ATB_ROWS * 128;
@@ -516,13 +522,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
     const bf16_t* obase = out + (size_t)s * L * Dm + h * 64;
     const bf16_t* gbase = dout + (size_t)s * L * Dm + h * 64;
 
-    // ---- staging: 144 rows x 8 chunks = 1152 16-B chunks per image, 256 threads, 5 sweeps (the last one half empty) ----
-    constexpr int SWEEPS = (ATB_ROWS * 8 + 255) / 256;
+    // ---- staging: 144 rows x 8 chunks = 1152 16-B chunks per image, NTH threads (256: 5 sweeps, the last one half empty) ----
+    constexpr int SWEEPS = (ATB_ROWS * 8 + NTH - 1) / NTH;
     uint4 lq[SWEEPS], lk[SWEEPS], lv[SWEEPS], lg[SWEEPS], lo[SWEEPS];
     float llse[SWEEPS];
 #pragma unroll
     for (int it = 0; it < SWEEPS; ++it) {
-        const int c = tid + it * 256, r = c >> 3, ch = c & 7;
+        const int c = tid + it * NTH, r = c >> 3, ch = c & 7;
         lq[it] = lk[it] = lv[it] = lg[it] = lo[it] = make_uint4(0, 0, 0, 0);
         llse[it] = 0.f;
         if (r < L) {
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
     }
 #pragma unroll
     for (int it = 0; it < SWEEPS; ++it) {
-        const int c = tid + it * 256, r = c >> 3, ch = c & 7;
+        const int c = tid + it * NTH, r = c >> 3, ch = c & 7;
         if (c < ATB_ROWS * 8) {
             const int off = d_off(r, ch);
             *(uint4*)(sQ + off) = lq[it];
@@ -565,8 +571,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
     const int tq = fr >> 2, tp = fr & 3;
     const float scale = 0.125f, c2 = scale * 1.4426950408889634f;
 
-    // ---- row / column x, step 1: the 4 x 129 raw dot products, one operand pair per wave ----
-    {
+    // ---- row / column x, step 1: the 4 x 129 raw dot products, one operand pair per wave (waves 0..3) ----
+    if (wave < 4) {
         const char* rows_img = wave == 0 ? sQ : wave == 1 ? sG : wave == 2 ? sK : sV;     // the 129 rows ...
         const char* vec_img = wave == 0 ? sK : wave == 1 ? sV : wave == 2 ? sQ : sG;      // ... against row x of this image
         float* dst = wave == 0 ? colS : wave == 1 ? colD : wave == 2 ? rowS : rowD;
@@ -631,11 +637,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
     // A wave owns query tiles (wave, wave + 4) and walks the keys ONCE for both: every K / V fragment and every transposed K
     // fragment read from LDS feeds two MFMAs instead of one (the arithmetic phases sit on LDS reads, profiles/r03_experiments.md).
     {
-        const int qa[2] = {wave * 16 + fr, (wave + 4) * 16 + fr};
-        bf16x8_t qf[2][2], gf[2][2];
-        float lq2[2], dqs[2];
+        int qa[PAIR];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < PAIR; ++t) qa[t] = (wave + t * NW) * 16 + fr;
+        bf16x8_t qf[PAIR][2], gf[PAIR][2];
+        float lq2[PAIR], dqs[PAIR];
+#pragma unroll
+        for (int t = 0; t < PAIR; ++t) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 qf[t][ks] = *(const bf16x8_t*)(sQ + d_off(qa[t], (ks << 2) | g));
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
             lq2[t] = sLse[qa[t]];
             dqs[t] = sDel[qa[t]];
         }
-        f32x4_t ds[2][ATX_NT];
+        f32x4_t ds[PAIR][ATX_NT];
 #pragma unroll
         for (int kt = 0; kt < ATX_NT; ++kt) {
             bf16x8_t kf[2], vf[2];
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
                 vf[ks] = *(const bf16x8_t*)(sV + d_off(kt * 16 + fr, (ks << 2) | g));
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < PAIR; ++t) {
                 f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -670,16 +678,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
             }
         }
         // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
-        f32x4_t o[2][4];
+        f32x4_t o[PAIR][4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < PAIR; ++t)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < ATX_NT / 2; ++kk) {
-            bf16x8_t pf[2];
+            bf16x8_t pf[PAIR];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < PAIR; ++t) {
                 const f32x4_t p0 = ds[t][2 * kk], p1 = ds[t][2 * kk + 1];
                 union { uint32_t w[4]; bf16x8_t v; } pk;
                 pk.w[0] = pack2_t<DT>(p0[0], p0[1]); pk.w[1] = pack2_t<DT>(p0[2], p0[3]);
@@ -693,44 +701,48 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
                 const bf16x4_t v0 = lds_tr16(sK + d_off(r0, chunk) + ((tp & 1) << 3));
                 const bf16x4_t v1 = lds_tr16(sK + d_off(r0 + 16, chunk) + ((tp & 1) << 3));
                 const bf16x8_t kT = (bf16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o[0][dt] = mfma16<DT>(kT, pf[0], o[0][dt]);
-                o[1][dt] = mfma16<DT>(kT, pf[1], o[1][dt]);
+#pragma unroll
+                for (int t = 0; t < PAIR; ++t) o[t][dt] = mfma16<DT>(kT, pf[t], o[t][dt]);
             }
         }
         // + dS[q, x] k_x: lane (fr, g) holds columns dt*16 + 4g .. +3 of query fr
         {
-            const float dsx[2] = {colD[qa[0]], colD[qa[1]]};
+            float dsx[PAIR];
+#pragma unroll
+            for (int t = 0; t < PAIR; ++t) dsx[t] = colD[qa[t]];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const uint2 m2 = *(const uint2*)(sK + d_off(XR, 2 * dt + (g >> 1)) + ((g & 1) << 3));
                 const float kx[4] = {cvt16f_t<DT>((bf16_t)(m2.x & 0xffff)), cvt16f_t<DT>((bf16_t)(m2.x >> 16)),
                                      cvt16f_t<DT>((bf16_t)(m2.y & 0xffff)), cvt16f_t<DT>((bf16_t)(m2.y >> 16))};
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < PAIR; ++t)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[t][dt][e] = __builtin_fmaf(dsx[t], kx[e], o[t][dt][e]);
             }
         }
-        store_rows16<DT>(o[0], dqkv + ((size_t)s * L + qa[0]) * D3 + h * 64, true, g);
-        store_rows16<DT>(o[1], dqkv + ((size_t)s * L + qa[1]) * D3 + h * 64, true, g);
+#pragma unroll
+        for (int t = 0; t < PAIR; ++t) store_rows16<DT>(o[t], dqkv + ((size_t)s * L + qa[t]) * D3 + h * 64, true, g);
     }
 
     // ------------------------------ pass B: dK, dV of rows 0..127 ------------------------------
     // the wave's two key tiles (wave, wave + 4) walk the queries together: Q / dO fragments, lse / delta and the transposed
     // dO / Q fragments are read once for both
     {
-        const int ka[2] = {wave * 16 + fr, (wave + 4) * 16 + fr};
-        bf16x8_t kf[2][2], vf[2][2];
+        int ka[PAIR];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < PAIR; ++t) ka[t] = (wave + t * NW) * 16 + fr;
+        bf16x8_t kf[PAIR][2], vf[PAIR][2];
+#pragma unroll
+        for (int t = 0; t < PAIR; ++t)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 kf[t][ks] = *(const bf16x8_t*)(sK + d_off(ka[t], (ks << 2) | g));
                 vf[t][ks] = *(const bf16x8_t*)(sV + d_off(ka[t], (ks << 2) | g));
             }
-        f32x4_t dk[2][4], dv[2][4];
+        f32x4_t dk[PAIR][4], dv[PAIR][4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < PAIR; ++t)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 dk[t][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
             }
 #pragma unroll 2      // (fully unrolled the four accumulator sets and four k-steps' fragments spill)
         for (int qq = 0; qq < ATX_NT / 2; ++qq) {  // query tiles (2qq, 2qq+1) = one 32-deep k-step
-            uint32_t pw[2][4], sw[2][4];
+            uint32_t pw[PAIR][4], sw[PAIR][4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * qq + half;
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
                 }
                 const f32x4_t l4 = *(const f32x4_t*)(sLse + qt * 16 + 4 * g), d4 = *(const f32x4_t*)(sDel + qt * 16 + 4 * g);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < PAIR; ++t) {
                     f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
@@ -767,9 +779,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
                     sw[t][half * 2] = pack2_t<DT>(dsv[0], dsv[1]); sw[t][half * 2 + 1] = pack2_t<DT>(dsv[2], dsv[3]);
                 }
             }
-            bf16x8_t pf[2], sf[2];
+            bf16x8_t pf[PAIR], sf[PAIR];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < PAIR; ++t) {
                 union { uint32_t w[4]; bf16x8_t v; } pu, su;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { pu.w[e] = pw[t][e]; su.w[e] = sw[t][e]; }
@@ -787,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
                 const bf16x8_t gT = (bf16x8_t){g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
                 const bf16x8_t qT = (bf16x8_t){q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < PAIR; ++t) {
                     dv[t][dt] = mfma16<DT>(gT, pf[t], dv[t][dt]);
                     dk[t][dt] = mfma16<DT>(qT, sf[t], dk[t][dt]);
                 }
@@ -795,7 +807,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
         }
         // + dS[x, key] q_x and P[x, key] dO_x: lane (fr, g) holds columns dt*16 + 4g .. +3 of key fr
         {
-            const float rds[2] = {rowD[ka[0]], rowD[ka[1]]}, rp[2] = {rowS[ka[0]], rowS[ka[1]]};
+            float rds[PAIR], rp[PAIR];
+#pragma unroll
+            for (int t = 0; t < PAIR; ++t) { rds[t] = rowD[ka[t]]; rp[t] = rowS[ka[t]]; }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int off = d_off(XR, 2 * dt + (g >> 1)) + ((g & 1) << 3);
@@ -805,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
                 const float gx[4] = {cvt16f_t<DT>((bf16_t)(g2.x & 0xffff)), cvt16f_t<DT>((bf16_t)(g2.x >> 16)),
                                      cvt16f_t<DT>((bf16_t)(g2.y & 0xffff)), cvt16f_t<DT>((bf16_t)(g2.y >> 16))};
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < PAIR; ++t)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         dk[t][dt][e] = __builtin_fmaf(rds[t], qx[e], dk[t][dt][e]);
@@ -814,12 +828,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_x1_kernel(const bf16_t* __res
             }
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < PAIR; ++t) {
             bf16_t* krow = dqkv + ((size_t)s * L + ka[t]) * D3 + Dm + h * 64;
             store_rows16<DT>(dk[t], krow, true, g);
             store_rows16<DT>(dv[t], krow + Dm, true, g);
         }
     }
+}
+
+// waves per block of the L = 129 backward: 8 (one tile per wave, default) or 4 (two tiles per wave); SIG_ATTN_BWD_WAVES / sig_tune_attn_bwd_waves
+static std::atomic<int> g_attn_bwd_waves{-1};
+static int attn_bwd_waves() {
+    int v = g_attn_bwd_waves.load();
+    if (v < 0) {
+        const char* e = getenv("SIG_ATTN_BWD_WAVES");
+        v = e ? (atoi(e) == 4 ? 4 : 8) : (SIG_ATTN_BWD_WAVES8_DEFAULT ? 8 : 4);
+        g_attn_bwd_waves = v;
+    }
+    return v;
+}
+int sig_tune_attn_bwd_waves_impl(int waves) {
+    const int prev = attn_bwd_waves();      // (resolves the environment preset first: restoring `prev` keeps it)
+    g_attn_bwd_waves = waves == 4 ? 4 : 8;
+    return prev;
 }
 
 template <int DT>
@@ -836,8 +867,12 @@ static void launch_attn_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* 
     if (x1 && L == 16 * ATX_NT + 1) {
         const int ldsx = lds + 4 * 132 * 4;
         static std::once_flag attr_x1;
-        std::call_once(attr_x1, [ldsx] { (void)hipFuncSetAttribute((const void*)&attn_bwd_x1_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsx); });
-        hipLaunchKernelGGL((attn_bwd_x1_kernel<DT>), dim3(S * H), dim3(256), ldsx, st, qkv, out, dout, lse, dqkv, S, H);
+        std::call_once(attr_x1, [ldsx] {
+            (void)hipFuncSetAttribute((const void*)&attn_bwd_x1_kernel<DT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
+            (void)hipFuncSetAttribute((const void*)&attn_bwd_x1_kernel<DT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);
+            });
+        if (attn_bwd_waves() == 8) hipLaunchKernelGGL((attn_bwd_x1_kernel<DT, 1>), dim3(S * H), dim3(512), ldsx, st, qkv, out, dout, lse, dqkv, S, H);
+        else hipLaunchKernelGGL((attn_bwd_x1_kernel<DT, 2>), dim3(S * H), dim3(256), ldsx, st, qkv, out, dout, lse, dqkv, S, H);
         return;
     }
     if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL((attn_bwd_kernel<true, DT>), dim3(S * H), dim3(192), lds, st, qkv, out, dout, lse, dqkv, S, L, H);

@@ -367,6 +367,16 @@ def test_attention_fwd_bwd(dev, dt16, s, l, h):
     assert rel_err(hv, gv) < 1e-2 * T
     assert rel_err(hk, gk) < 1.5e-2 * T
     assert rel_err(hq, gq) < 1.5e-2 * T
+    if l == 129:        # the two forms of the L = 16 * 8 + 1 backward (eight waves x one tile, four waves x two tiles): same arithmetic
+        from signal_amd import _lib
+        lib = _lib.load()
+        prev = lib.sig_tune_attn_bwd_waves(4)
+        try:
+            dq4 = torch.zeros_like(qkv_p)
+            ops.attn_bwd(qkv_p, out, padded(dout, ops), lse, dq4, s, l, h)
+        finally:
+            lib.sig_tune_attn_bwd_waves(prev)
+        assert prev == 8 and torch.equal(dq4, dqkv), "four-wave and eight-wave attention backward differ"
 
 
 def test_cast_transpose_colsum(dev, dt16):
