@@ -53,6 +53,9 @@ int sig_tune_nt_persist(int on);
  * 16-row tile per wave and pass (default; two resident workgroups put four waves on a SIMD), 4 = two tiles per wave sharing their
  * fragment reads.  Bit-identical results; returns the previous setting.  Environment preset: SIG_ATTN_BWD_WAVES. */
 int sig_tune_attn_bwd_waves(int waves);
+/* Same for the attention forward at L in (128, 144]: 9 = one 16-row query tile per wave (default: nine waves' q-fragment loads and
+ * softmax chains in flight at once, 70 registers), 3 = three tiles per wave, one after the other.  Bit-identical results. */
+int sig_tune_attn_fwd_waves(int waves);
 /* Same for the weight-gradient path: 128 = the 128x128-tile kernel with f32 atomics, one launch per weight; 256 = the 256x256
  * kernel, one launch per weight; 0 = default (a block's four weights grouped into one launch).  Environment: SIG_GEMM_TN_TILE. */
 int sig_tune_tn_path(int path);

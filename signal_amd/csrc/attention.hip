@@ -35,8 +35,10 @@ __device__ __forceinline__ int v_off(int row, int chunk) { return row * 128 + ((
 
 // FULL: L in (128, 144], i.e. all nine 16-row tiles exist (every shipped config: L = 129) -- the per-tile guards fold away;
 // with a run-time tile count the ~50 live scalar conditions were spilled to VGPR lanes (v_writelane / v_readlane).
-template <bool FULL, int DT>
-__global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// NW = waves per block: 3 (three query tiles per wave, one after the other) or 9 (one tile per wave: nine waves' q-fragment loads and
+// softmax chains in flight at once; FULL only)
+template <bool FULL, int DT, int NW = 3>
+__global__ __launch_bounds__(64 * NW, NW == 3 ? 3 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int S, int L, int H) {
     __shared__ __attribute__((aligned(16))) char smem[ATT_KROWS * 128 + ATT_VROWS * 128];
 #ifdef SIG_ATTN_STAMPS
@@ -52,29 +54,30 @@ __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restri
 
     // K and V of the head: every load of a thread is requested before the first LDS write (sweep by sweep the HBM
     // latencies were serialised)
-    constexpr int KS = ATT_KROWS * 8 / 192, VS = (ATT_VROWS * 8 + 191) / 192;
-    static_assert(ATT_KROWS * 8 % 192 == 0, "K staging sweeps");
+    constexpr int NTH = 64 * NW;
+    constexpr int KS = ATT_KROWS * 8 / NTH, VS = (ATT_VROWS * 8 + NTH - 1) / NTH;
+    static_assert(ATT_KROWS * 8 % NTH == 0, "K staging sweeps");
     uint4 rk[KS], rv[VS];
 #pragma unroll
     for (int it = 0; it < KS; ++it) {
-        const int c = tid + it * 192, r = c >> 3, ch = c & 7;
+        const int c = tid + it * NTH, r = c >> 3, ch = c & 7;
         rk[it] = make_uint4(0, 0, 0, 0);
         if (r < L) rk[it] = *(const uint4*)(base + (size_t)r * D3 + Dm + ch * 8);
     }
 #pragma unroll
     for (int it = 0; it < VS; ++it) {
-        const int c = tid + it * 192, r = c >> 3, ch = c & 7;
+        const int c = tid + it * NTH, r = c >> 3, ch = c & 7;
         rv[it] = make_uint4(0, 0, 0, 0);
         if (c < ATT_VROWS * 8 && r < L) rv[it] = *(const uint4*)(base + (size_t)r * D3 + 2 * Dm + ch * 8);
     }
 #pragma unroll
     for (int it = 0; it < KS; ++it) {
-        const int c = tid + it * 192;
+        const int c = tid + it * NTH;
         *(uint4*)(sK + k_off(c >> 3, c & 7)) = rk[it];
     }
 #pragma unroll
     for (int it = 0; it < VS; ++it) {
-        const int c = tid + it * 192;
+        const int c = tid + it * NTH;
         if (c < ATT_VROWS * 8) *(uint4*)(sV + v_off(c >> 3, c & 7)) = rv[it];
     }
     __syncthreads();
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restri
     const float scale = 0.125f;
 
 #pragma unroll 1   // (with a constant tile count the compiler would unroll the three tiles: 336 registers)
-    for (int qt = wave; qt < NT; qt += 3) {
+    for (int qt = wave; qt < NT; qt += NW) {
         const int q = qt * 16 + fr;
         const int qc = q < L ? q : L - 1;
         bf16x8_t qf[2];
@@ -192,10 +195,32 @@ __global__ __launch_bounds__(192, 3) void attn_fwd_kernel(const bf16_t* __restri
 #endif
 }
 
+// waves per block of the forward at L in (128, 144]: 9 (one query tile per wave, default) or 3 (three tiles per wave, one after the
+// other); SIG_ATTN_FWD_WAVES / sig_tune_attn_fwd_waves
+static std::atomic<int> g_attn_fwd_waves{-1};
+static int attn_fwd_waves() {
+    int v = g_attn_fwd_waves.load();
+    if (v < 0) {
+        const char* e = getenv("SIG_ATTN_FWD_WAVES");
+        v = e && atoi(e) == 3 ? 3 : 9;
+        g_attn_fwd_waves = v;
+    }
+    return v;
+}
+int sig_tune_attn_fwd_waves_impl(int waves) {
+    const int prev = attn_fwd_waves();
+    g_attn_fwd_waves = waves == 3 ? 3 : 9;
+    return prev;
+}
+
 template <int DT>
 static void launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, hipStream_t st) {
-    if (L > 16 * (ATT_NT - 1)) hipLaunchKernelGGL((attn_fwd_kernel<true, DT>), dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false, DT>), dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
+    if (L > 16 * (ATT_NT - 1)) {
+        if (attn_fwd_waves() == 9) hipLaunchKernelGGL((attn_fwd_kernel<true, DT, 9>), dim3(S * H), dim3(576), 0, st, qkv, out, lse, S, L, H);
+        else hipLaunchKernelGGL((attn_fwd_kernel<true, DT>), dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
+    } else {
+        hipLaunchKernelGGL((attn_fwd_kernel<false, DT>), dim3(S * H), dim3(192), 0, st, qkv, out, lse, S, L, H);
+    }
 }
 int sig_launch_attn_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int S, int L, int H, int dt, hipStream_t st) {
     SIG_CHECK_DT(dt, "attn_fwd");

@@ -30,6 +30,7 @@ int sig_tune_gemm_tile(int tile) { return sig_tune_gemm_tile_impl(tile); }
 int sig_tune_nt_persist(int on) { return sig_tune_nt_persist_impl(on); }
 int sig_tune_ln_defer(int on) { return sig_tune_ln_defer_impl(on); }
 int sig_tune_attn_bwd_waves(int waves) { return sig_tune_attn_bwd_waves_impl(waves); }
+int sig_tune_attn_fwd_waves(int waves) { return sig_tune_attn_fwd_waves_impl(waves); }
 int sig_ln_flush(void* stream) { return sig_ln_flush_impl((hipStream_t)stream); }
 int sig_tune_reserved_cus(int n) { return sig_tune_reserved_cus_impl(n); }
 int sig_tune_tn_path(int path) { return sig_tune_tn_path_impl(path); }

@@ -88,6 +88,7 @@ int sig_launch_layernorm_fwd(const float* x, const float* gamma, const float* be
 int sig_launch_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                              const float* rstd, const float* dres, float* dx_f32, bf16_t* dx_bf16, float* dgamma,
                              float* dbeta, int M, int D, int dt, hipStream_t st, float* dx_colsum = nullptr);
+int sig_tune_attn_fwd_waves_impl(int waves);   // 9 (default) or 3 waves per block of the attention forward at L in (128, 144]
 int sig_tune_attn_bwd_waves_impl(int waves);   // 8 (default) or 4 waves per block of the L = 129 attention backward (attention.hip)
 int sig_tune_ln_defer_impl(int on);           // chained column reduce of consecutive LayerNorm backwards (rowops.hip)
 int sig_ln_flush_impl(hipStream_t st);

@@ -377,6 +377,16 @@ def test_attention_fwd_bwd(dev, dt16, s, l, h):
         finally:
             lib.sig_tune_attn_bwd_waves(prev)
         assert prev == 8 and torch.equal(dq4, dqkv), "four-wave and eight-wave attention backward differ"
+    if l > 128:         # ... and of the forward (nine waves x one query tile, three waves x three tiles)
+        from signal_amd import _lib
+        lib = _lib.load()
+        prev = lib.sig_tune_attn_fwd_waves(3)
+        try:
+            out3, lse3 = torch.zeros_like(out), torch.zeros_like(lse)
+            ops.attn_fwd(qkv_p, out3, lse3, s, l, h)
+        finally:
+            lib.sig_tune_attn_fwd_waves(prev)
+        assert prev == 9 and torch.equal(out3, out) and torch.equal(lse3, lse), "three-wave and nine-wave attention forward differ"
 
 
 def test_cast_transpose_colsum(dev, dt16):
