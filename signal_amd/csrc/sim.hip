@@ -302,7 +302,7 @@ int sig_launch_sim_gather_bwd(const bf16_t* dsel, const float* dcls, const float
 }
 
 // ------------------------------------------------------------------------------------------------
-// cross-attention core: 3 queries x NK keys x 8 heads of 64 (useA.py:388), one workgroup per sample.
+// cross-attention core: 3 queries x NK keys x 8 heads of 64 (useA.py:388), one workgroup per (sample, head).
 //   q   f32  [B*3, 512]            (already projected, bias added)
 //   kv  bf16 [B*NK, 1024]          (k | v, bias added)
 //   out bf16 [B*3, 512]            heads re-concatenated
@@ -310,40 +310,42 @@ int sig_launch_sim_gather_bwd(const bf16_t* dsel, const float* dcls, const float
 // ------------------------------------------------------------------------------------------------
 #define XA_H 8
 #define XA_MAXK 384
+// One workgroup per (sample, head): 512 blocks at B = 64 instead of 64, and the loops over the keys are split over the eight waves
+// (wave w takes keys w, w + 8, ...; the eight partial sums are added in wave order: deterministic).  With one workgroup per sample
+// every thread walked all NK keys alone: 48 us forward / 96 us backward for 50 MB.
 __global__ __launch_bounds__(512) void xattn_fwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv, int NK,
                                                         bf16_t* __restrict__ out, float* __restrict__ probs, int dt) {
-    __shared__ float sq[3 * SIM_D];
-    __shared__ float sp[24][XA_MAXK];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 3 * SIM_D; i += 512) sq[i] = q[(size_t)b * 3 * SIM_D + i];
+    __shared__ float sq[3][64];
+    __shared__ float sp[3][XA_MAXK];
+    __shared__ float part[3][8][64];
+    const int b = blockIdx.x / XA_H, h = blockIdx.x - b * XA_H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 192) sq[tid >> 6][lane] = q[((size_t)b * 3 + (tid >> 6)) * SIM_D + h * 64 + lane];
     __syncthreads();
     // scores: thread = key
     if (tid < NK) {
-        const bf16_t* krow = kv + ((size_t)b * NK + tid) * 1024;
-#pragma unroll 1
-        for (int h = 0; h < XA_H; ++h) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const bf16_t* krow = kv + ((size_t)b * NK + tid) * 1024 + h * 64;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint4 u = *(const uint4*)(krow + h * 64 + c * 8);
-                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        for (int c = 0; c < 8; ++c) {
+            const uint4 u = *(const uint4*)(krow + c * 8);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float k0 = cvt16f((bf16_t)(w[e] & 0xffff), dt), k1 = cvt16f((bf16_t)(w[e] >> 16), dt);
-                    const int d = h * 64 + c * 8 + e * 2;
-                    a0 += k0 * sq[d] + k1 * sq[d + 1];
-                    a1 += k0 * sq[SIM_D + d] + k1 * sq[SIM_D + d + 1];
-                    a2 += k0 * sq[2 * SIM_D + d] + k1 * sq[2 * SIM_D + d + 1];
-                }
+            for (int e = 0; e < 4; ++e) {
+                const float k0 = cvt16f((bf16_t)(w[e] & 0xffff), dt), k1 = cvt16f((bf16_t)(w[e] >> 16), dt);
+                const int d = c * 8 + e * 2;
+                a0 += k0 * sq[0][d] + k1 * sq[0][d + 1];
+                a1 += k0 * sq[1][d] + k1 * sq[1][d + 1];
+                a2 += k0 * sq[2][d] + k1 * sq[2][d + 1];
             }
-            sp[h * 3 + 0][tid] = a0 * 0.125f;
-            sp[h * 3 + 1][tid] = a1 * 0.125f;
-            sp[h * 3 + 2][tid] = a2 * 0.125f;
         }
+        sp[0][tid] = a0 * 0.125f;
+        sp[1][tid] = a1 * 0.125f;
+        sp[2][tid] = a2 * 0.125f;
     }
     __syncthreads();
-    // softmax per (head, query) row: 8 waves x 3 rows
-    for (int r = wave; r < 24; r += 8) {
+    // softmax of the head's three query rows: one wave each
+    if (wave < 3) {
+        const int r = wave;
         float mx = -INFINITY;
         for (int j = lane; j < NK; j += 64) mx = fmaxf(mx, sp[r][j]);
         mx = wave_max(mx);
@@ -357,24 +359,30 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(const float* __restrict_
         for (int j = lane; j < NK; j += 64) {
             const float pv = sp[r][j] * sm;
             sp[r][j] = pv;
-            if (probs) probs[((size_t)b * 24 + r) * NK + j] = pv;
+            if (probs) probs[((size_t)b * 24 + h * 3 + r) * NK + j] = pv;
         }
     }
     __syncthreads();
-    // out[qi][c] = sum_j p[h(c)*3+qi][j] v[j][c] : thread = column
+    // out[qi][c] = sum_j p[qi][j] v[j][c]: lane = column of the head, wave = key group
     {
-        const int c = tid, h = c >> 6;
-        const bf16_t* vcol = kv + (size_t)b * NK * 1024 + 512 + c;
+        const bf16_t* vcol = kv + (size_t)b * NK * 1024 + 512 + h * 64 + lane;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int j = 0; j < NK; ++j) {
+#pragma unroll 4
+        for (int j = wave; j < NK; j += 8) {
             const float v = cvt16f(vcol[(size_t)j * 1024], dt);
-            a0 += sp[h * 3 + 0][j] * v;
-            a1 += sp[h * 3 + 1][j] * v;
-            a2 += sp[h * 3 + 2][j] * v;
+            a0 += sp[0][j] * v;
+            a1 += sp[1][j] * v;
+            a2 += sp[2][j] * v;
         }
-        out[((size_t)b * 3 + 0) * SIM_D + c] = f2cvt16(a0, dt);
-        out[((size_t)b * 3 + 1) * SIM_D + c] = f2cvt16(a1, dt);
-        out[((size_t)b * 3 + 2) * SIM_D + c] = f2cvt16(a2, dt);
+        part[0][wave][lane] = a0; part[1][wave][lane] = a1; part[2][wave][lane] = a2;
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int qi = tid >> 6;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += part[qi][w][lane];
+        out[((size_t)b * 3 + qi) * SIM_D + h * 64 + lane] = f2cvt16(t, dt);
     }
 }
 
@@ -382,62 +390,54 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
                                                         const float* __restrict__ probs, const float* __restrict__ dout, int NK,
                                                         float* __restrict__ dq, bf16_t* __restrict__ dkv, int dt) {
-    __shared__ float sq[3 * SIM_D], sdo[3 * SIM_D];
-    __shared__ float sp[24][XA_MAXK];   // probs, then dS (scaled)
-    __shared__ float sdelta[24];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 3 * SIM_D; i += 512) {
-        sq[i] = q[(size_t)b * 3 * SIM_D + i];
-        sdo[i] = dout[(size_t)b * 3 * SIM_D + i];
+    __shared__ float sq[3][64], sdo[3][64];
+    __shared__ float sp[3][XA_MAXK];   // probs, then dS (scaled)
+    __shared__ float sdelta[3];
+    __shared__ float spart[3][8];
+    __shared__ float part[3][8][64];
+    const int b = blockIdx.x / XA_H, h = blockIdx.x - b * XA_H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 192) {
+        sq[tid >> 6][lane] = q[((size_t)b * 3 + (tid >> 6)) * SIM_D + h * 64 + lane];
+        sdo[tid >> 6][lane] = dout[((size_t)b * 3 + (tid >> 6)) * SIM_D + h * 64 + lane];
     }
-    for (int i = tid; i < 24 * NK; i += 512) sp[i / NK][i % NK] = probs[(size_t)b * 24 * NK + i];
+    for (int i = tid; i < 3 * NK; i += 512) sp[i / NK][i % NK] = probs[((size_t)b * 24 + h * 3) * NK + i];
     __syncthreads();
-    // dV[j][c] = sum_qi p[h*3+qi][j] dO[qi][c]   (thread = column, loop keys) -- written straight to dkv
+    // dV[j][c] = sum_qi p[qi][j] dO[qi][c]   (lane = column of the head, wave = key group) -- written straight to dkv
     {
-        const int c = tid, h = c >> 6;
-        const float d0 = sdo[c], d1 = sdo[SIM_D + c], d2 = sdo[2 * SIM_D + c];
-        bf16_t* dv = dkv + (size_t)b * NK * 1024 + 512 + c;
-        for (int j = 0; j < NK; ++j)
-            dv[(size_t)j * 1024] = f2cvt16(sp[h * 3 + 0][j] * d0 + sp[h * 3 + 1][j] * d1 + sp[h * 3 + 2][j] * d2, dt);
+        const float d0 = sdo[0][lane], d1 = sdo[1][lane], d2 = sdo[2][lane];
+        bf16_t* dv = dkv + (size_t)b * NK * 1024 + 512 + h * 64 + lane;
+#pragma unroll 4
+        for (int j = wave; j < NK; j += 8) dv[(size_t)j * 1024] = f2cvt16(sp[0][j] * d0 + sp[1][j] * d1 + sp[2][j] * d2, dt);
     }
-    __syncthreads();
-    // dP[r][j] = dO[qi, head h] . v[j, head h]; delta[r] = sum_j p dP; dS = p (dP - delta) / 8
-    float dpr[24];
+    // dP[qi][j] = dO[qi] . v[j] over the head's 64 dims; delta[qi] = sum_j p dP; dS = p (dP - delta) / 8
+    float dpr[3] = {0.f, 0.f, 0.f};
     if (tid < NK) {
-        const bf16_t* vrow = kv + ((size_t)b * NK + tid) * 1024 + 512;
+        const bf16_t* vrow = kv + ((size_t)b * NK + tid) * 1024 + 512 + h * 64;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int h = 0; h < XA_H; ++h) {  // fully unrolled: dpr[] must stay in registers
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int c = 0; c < 8; ++c) {
+            const uint4 u = *(const uint4*)(vrow + c * 8);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint4 u = *(const uint4*)(vrow + h * 64 + c * 8);
-                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v0 = cvt16f((bf16_t)(w[e] & 0xffff), dt), v1 = cvt16f((bf16_t)(w[e] >> 16), dt);
-                    const int d = h * 64 + c * 8 + e * 2;
-                    a0 += v0 * sdo[d] + v1 * sdo[d + 1];
-                    a1 += v0 * sdo[SIM_D + d] + v1 * sdo[SIM_D + d + 1];
-                    a2 += v0 * sdo[2 * SIM_D + d] + v1 * sdo[2 * SIM_D + d + 1];
-                }
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = cvt16f((bf16_t)(w[e] & 0xffff), dt), v1 = cvt16f((bf16_t)(w[e] >> 16), dt);
+                const int d = c * 8 + e * 2;
+                a0 += v0 * sdo[0][d] + v1 * sdo[0][d + 1];
+                a1 += v0 * sdo[1][d] + v1 * sdo[1][d + 1];
+                a2 += v0 * sdo[2][d] + v1 * sdo[2][d + 1];
             }
-            dpr[h * 3 + 0] = a0; dpr[h * 3 + 1] = a1; dpr[h * 3 + 2] = a2;
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 24; ++r) dpr[r] = 0.f;
+        dpr[0] = a0; dpr[1] = a1; dpr[2] = a2;
     }
-    // delta[r] = sum_j p dP: per-wave partials, added in wave order (LDS float atomics made the order, and with it the last
-    // bit of every dS, vary from run to run)
-    __shared__ float spart[24][8];
+    // delta: per-wave partials, added in wave order (deterministic)
 #pragma unroll
-    for (int r = 0; r < 24; ++r) {
+    for (int r = 0; r < 3; ++r) {
         float v = tid < NK ? sp[r][tid] * dpr[r] : 0.f;
         v = wave_sum(v);
         if (lane == 0) spart[r][wave] = v;
     }
-    __syncthreads();
-    if (tid < 24) {
+    __syncthreads();      // (also: every dV store above has read its probabilities)
+    if (tid < 3) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) t += spart[tid][w];
@@ -446,38 +446,40 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(const float* __restrict_
     __syncthreads();
     if (tid < NK) {
 #pragma unroll
-        for (int r = 0; r < 24; ++r) sp[r][tid] = sp[r][tid] * (dpr[r] - sdelta[r]) * 0.125f;
+        for (int r = 0; r < 3; ++r) sp[r][tid] = sp[r][tid] * (dpr[r] - sdelta[r]) * 0.125f;
     }
     __syncthreads();
-    // dK[j][h*64+d] = sum_qi dS[h*3+qi][j] q[qi][h*64+d]   (thread = column)
+    // dK[j][c] = sum_qi dS[qi][j] q[qi][c];  dq[qi][c] = sum_j dS[qi][j] k[j][c]  (lane = column, wave = key group)
     {
-        const int c = tid, h = c >> 6;
-        const float q0 = sq[c], q1 = sq[SIM_D + c], q2 = sq[2 * SIM_D + c];
-        bf16_t* dk = dkv + (size_t)b * NK * 1024 + c;
-        for (int j = 0; j < NK; ++j)
-            dk[(size_t)j * 1024] = f2cvt16(sp[h * 3 + 0][j] * q0 + sp[h * 3 + 1][j] * q1 + sp[h * 3 + 2][j] * q2, dt);
-    }
-    // dq[qi][c] = sum_j dS[h*3+qi][j] k[j][c]
-    {
-        const int c = tid, h = c >> 6;
-        const bf16_t* kcol = kv + (size_t)b * NK * 1024 + c;
+        const float q0 = sq[0][lane], q1 = sq[1][lane], q2 = sq[2][lane];
+        bf16_t* dk = dkv + (size_t)b * NK * 1024 + h * 64 + lane;
+        const bf16_t* kcol = kv + (size_t)b * NK * 1024 + h * 64 + lane;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int j = 0; j < NK; ++j) {
+#pragma unroll 4
+        for (int j = wave; j < NK; j += 8) {
+            const float s0 = sp[0][j], s1 = sp[1][j], s2 = sp[2][j];
+            dk[(size_t)j * 1024] = f2cvt16(s0 * q0 + s1 * q1 + s2 * q2, dt);
             const float k = cvt16f(kcol[(size_t)j * 1024], dt);
-            a0 += sp[h * 3 + 0][j] * k;
-            a1 += sp[h * 3 + 1][j] * k;
-            a2 += sp[h * 3 + 2][j] * k;
+            a0 += s0 * k;
+            a1 += s1 * k;
+            a2 += s2 * k;
         }
-        dq[((size_t)b * 3 + 0) * SIM_D + c] = a0;
-        dq[((size_t)b * 3 + 1) * SIM_D + c] = a1;
-        dq[((size_t)b * 3 + 2) * SIM_D + c] = a2;
+        part[0][wave][lane] = a0; part[1][wave][lane] = a1; part[2][wave][lane] = a2;
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int qi = tid >> 6;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += part[qi][w][lane];
+        dq[((size_t)b * 3 + qi) * SIM_D + h * 64 + lane] = t;
     }
 }
 
 int sig_launch_xattn_fwd(const float* q, const bf16_t* kv, int B, int NK, bf16_t* out, float* probs, int dt, hipStream_t st) {
     SIG_CHECK_DT(dt, "xattn_fwd");
     SIG_CHECK_ARG(q && kv && out && B > 0 && NK > 0 && NK <= XA_MAXK, "xattn_fwd: bad arguments (keys %d, max %d)", NK, XA_MAXK);
-    hipLaunchKernelGGL(xattn_fwd_kernel, dim3(B), dim3(512), 0, st, q, kv, NK, out, probs, dt);
+    hipLaunchKernelGGL(xattn_fwd_kernel, dim3(B * XA_H), dim3(512), 0, st, q, kv, NK, out, probs, dt);
     SIG_CHECK_LAUNCH("xattn_fwd");
     return 0;
 }
@@ -485,7 +487,7 @@ int sig_launch_xattn_bwd(const float* q, const bf16_t* kv, const float* probs, c
                          bf16_t* dkv, int dt, hipStream_t st) {
     SIG_CHECK_DT(dt, "xattn_bwd");
     SIG_CHECK_ARG(q && kv && probs && dout && dq && dkv && B > 0 && NK > 0 && NK <= XA_MAXK, "xattn_bwd: bad arguments");
-    hipLaunchKernelGGL(xattn_bwd_kernel, dim3(B), dim3(512), 0, st, q, kv, probs, dout, NK, dq, dkv, dt);
+    hipLaunchKernelGGL(xattn_bwd_kernel, dim3(B * XA_H), dim3(512), 0, st, q, kv, probs, dout, NK, dq, dkv, dt);
     SIG_CHECK_LAUNCH("xattn_bwd");
     return 0;
 }
