@@ -546,6 +546,10 @@ __global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t
     const bf16_t* base = qkv + (size_t)s * L * D3 + h * 64;
     const bf16_t* obase = out + (size_t)s * L * Dm + h * 64;
     const bf16_t* gbase = dout + (size_t)s * L * Dm + h * 64;
+#ifdef SIG_ATTN_STAMPS
+    unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0;
+    ATT_STAMP(ta0);
+#endif
 
     // ---- staging: 144 rows x 8 chunks = 1152 16-B chunks per image, NTH threads (256: 5 sweeps, the last one half empty) ----
     constexpr int SWEEPS = (ATB_ROWS * 8 + NTH - 1) / NTH;
@@ -595,6 +599,9 @@ __global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t
     const int fr = lane & 15, g = lane >> 4;
     const int tq = fr >> 2, tp = fr & 3;
     const float scale = 0.125f, c2 = scale * 1.4426950408889634f;
+#if defined(SIG_ATTN_STAMPS) && SIG_ATTN_STAMPS != 2
+    ATT_STAMP(ta1);
+#endif
 
     // ---- row / column x, step 1: the 4 x 129 raw dot products, one operand pair per wave (waves 0..3) ----
     if (wave < 4) {
@@ -658,6 +665,9 @@ __global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t
         }
     }
 
+#if defined(SIG_ATTN_STAMPS) && SIG_ATTN_STAMPS == 2      // (variant: second stamp after the row-x steps instead of after staging)
+    ATT_STAMP(ta1);
+#endif
     // ------------------------------ pass A: dQ of rows 0..127 ------------------------------
     // A wave owns query tiles (wave, wave + 4) and walks the keys ONCE for both: every K / V fragment and every transposed K
     // fragment read from LDS feeds two MFMAs instead of one (the arithmetic phases sit on LDS reads, profiles/r03_experiments.md).
@@ -750,6 +760,9 @@ __global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t
         for (int t = 0; t < PAIR; ++t) store_rows16<DT>(o[t], dqkv + ((size_t)s * L + qa[t]) * D3 + h * 64, true, g);
     }
 
+#ifdef SIG_ATTN_STAMPS
+    ATT_STAMP(ta2);
+#endif
     // ------------------------------ pass B: dK, dV of rows 0..127 ------------------------------
     // the wave's two key tiles (wave, wave + 4) walk the queries together: Q / dO fragments, lse / delta and the transposed
     // dO / Q fragments are read once for both
@@ -859,6 +872,14 @@ __global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t
             store_rows16<DT>(dv[t], krow + Dm, true, g);
         }
     }
+#ifdef SIG_ATTN_STAMPS      // tools/attn_stamps.py: staging | row-x steps + pass A | pass B + store drain (wave 0's view; =2: staging + row-x steps | pass A)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_STAMP(ta3);
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_astamps[blockIdx.x * 4 + 0] = ta0; g_astamps[blockIdx.x * 4 + 1] = ta1;
+        g_astamps[blockIdx.x * 4 + 2] = ta2; g_astamps[blockIdx.x * 4 + 3] = ta3;
+    }
+#endif
 }
 
 // waves per block of the L = 129 backward: 8 (one tile per wave, default) or 4 (two tiles per wave); SIG_ATTN_BWD_WAVES / sig_tune_attn_bwd_waves

@@ -8,7 +8,7 @@ csrc = os.path.join(ROOT, "signal_amd", "csrc")
 tmp = tempfile.mkdtemp(); lib = os.path.join(tmp, "libsignal_hip_astamps.so")
 srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hip")]
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffast-math",
-                "-fno-finite-math-only", "-DSIG_ATTN_STAMPS", "-I" + os.path.join(ROOT, "include"), "-shared", "-o", lib, *srcs], check=True, capture_output=True)
+                "-fno-finite-math-only", "-DSIG_ATTN_STAMPS=" + os.environ.get("STAMPS_VARIANT", "1"), "-I" + os.path.join(ROOT, "include"), "-shared", "-o", lib, *srcs], check=True, capture_output=True)
 import torch
 from signal_amd import _lib, ops
 _lib.LIB_PATH = lib; _lib._lib = None; L_ = _lib.load()
