@@ -518,6 +518,13 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
 //   pass A / pass B just before they are stored (16 FMAs per lane and tile).
 // Everything else (dual-use LDS images, passes A and B, in-register dS) is the kernel above with 8 tiles.
 // ------------------------------------------------------------------------------------------------
+// c + a.lo * b.lo + a.hi * b.hi on two packed 16-bit pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16): no conversions, one instruction
+template <int DT> __device__ __forceinline__ float dot2_t(uint32_t a, uint32_t b, float c) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    if (DT == SIG_DT_F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, b), c, false);
+}
 #define ATX_NT 8
 #ifndef SIG_ATTN_BWD_WAVES8_DEFAULT
 #define SIG_ATTN_BWD_WAVES8_DEFAULT 1
@@ -582,10 +589,7 @@ __global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t
         const uint32_t gw[4] = {lg[it].x, lg[it].y, lg[it].z, lg[it].w}, ow[4] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w};
         float d = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            d += cvt16f_t<DT>((bf16_t)(gw[e] & 0xffff)) * cvt16f_t<DT>((bf16_t)(ow[e] & 0xffff));
-            d += cvt16f_t<DT>((bf16_t)(gw[e] >> 16)) * cvt16f_t<DT>((bf16_t)(ow[e] >> 16));
-        }
+        for (int e = 0; e < 4; ++e) d = dot2_t<DT>(gw[e], ow[e], d);
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
         d += __shfl_xor(d, 4, 64);
@@ -603,29 +607,22 @@ __global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t
     ATT_STAMP(ta1);
 #endif
 
-    // ---- row / column x, step 1: the 4 x 129 raw dot products, one operand pair per wave (waves 0..3) ----
-    if (wave < 4) {
-        const char* rows_img = wave == 0 ? sQ : wave == 1 ? sG : wave == 2 ? sK : sV;     // the 129 rows ...
-        const char* vec_img = wave == 0 ? sK : wave == 1 ? sV : wave == 2 ? sQ : sG;      // ... against row x of this image
-        float* dst = wave == 0 ? colS : wave == 1 ? colD : wave == 2 ? rowS : rowD;
-        uint4 xw[8];                           // row x of the other operand, 16-bit as staged (converted on the fly)
+    // ---- row / column x, step 1: the 4 x 129 raw dot products of 64, spread over all threads (512 threads: one each) ----
+    for (int idx = tid; idx < 4 * L; idx += NTH) {
+        const int pr = idx / L, r = idx - pr * L;                                          // operand pair, row
+        const char* rows_img = pr == 0 ? sQ : pr == 1 ? sG : pr == 2 ? sK : sV;            // row r of this image ...
+        const char* vec_img = pr == 0 ? sK : pr == 1 ? sV : pr == 2 ? sQ : sG;             // ... against row x of this one
+        float* dst = pr == 0 ? colS : pr == 1 ? colD : pr == 2 ? rowS : rowD;
+        float a0 = 0.f, a1 = 0.f;             // (two chains; 32 packed two-element dot products in all)
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) xw[ch] = *(const uint4*)(vec_img + d_off(XR, ch));
-#pragma unroll 1
-        for (int r = lane; r < L; r += 64) {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                const uint4 w4 = *(const uint4*)(rows_img + d_off(r, ch));
-                const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w}, x[4] = {xw[ch].x, xw[ch].y, xw[ch].z, xw[ch].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a0 = __builtin_fmaf(cvt16f_t<DT>((bf16_t)(w[e] & 0xffff)), cvt16f_t<DT>((bf16_t)(x[e] & 0xffff)), a0);
-                    a1 = __builtin_fmaf(cvt16f_t<DT>((bf16_t)(w[e] >> 16)), cvt16f_t<DT>((bf16_t)(x[e] >> 16)), a1);
-                }
-            }
-            dst[r] = a0 + a1;
+        for (int ch = 0; ch < 8; ++ch) {
+            const uint4 w4 = *(const uint4*)(rows_img + d_off(r, ch)), x4 = *(const uint4*)(vec_img + d_off(XR, ch));
+            a0 = dot2_t<DT>(w4.x, x4.x, a0);
+            a1 = dot2_t<DT>(w4.y, x4.y, a1);
+            a0 = dot2_t<DT>(w4.z, x4.z, a0);
+            a1 = dot2_t<DT>(w4.w, x4.w, a1);
         }
+        dst[r] = a0 + a1;
     }
     __syncthreads();
     // ---- step 2: probabilities and dS of column x (per query i) and row x (per key j), in place ----
@@ -639,29 +636,46 @@ __global__ __launch_bounds__(512 / PAIR, 2) void attn_bwd_x1_kernel(const bf16_t
     }
     __syncthreads();
     // ---- step 3: the three outputs of row x -- dQ[x] = sum_j dS[x,j] K[j], dK[x] = sum_i dS[i,x] Q[i], dV[x] = sum_i P[i,x] dO[i]
-    //      (the (x, x) term is inside: column x and row x meet there) -- one per wave; a lane owns 4 columns and every 4th row
+    //      (the (x, x) term is inside: column x and row x meet there) -- one per wave, on the matrix cores: the transposed image
+    //      fragments of passes A / B against a B operand whose ONLY non-zero column is the weight vector (lanes fr == 0), five
+    //      32-deep steps (the fifth holds row 128 alone); the weights are rounded to the operand type like every other row's.
     if (wave < 3) {
         const float* wv = wave == 0 ? rowD : wave == 1 ? colD : colS;
         const char* img = wave == 0 ? sK : wave == 1 ? sQ : sG;
-        const int rq = lane >> 4, c4 = lane & 15;
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int r = rq; r < L; r += 4) {
-            const float wgt = wv[r];
-            const uint2 m2 = *(const uint2*)(img + d_off(r, c4 >> 1) + ((c4 & 1) << 3));
-            a[0] = __builtin_fmaf(wgt, cvt16f_t<DT>((bf16_t)(m2.x & 0xffff)), a[0]);
-            a[1] = __builtin_fmaf(wgt, cvt16f_t<DT>((bf16_t)(m2.x >> 16)), a[1]);
-            a[2] = __builtin_fmaf(wgt, cvt16f_t<DT>((bf16_t)(m2.y & 0xffff)), a[2]);
-            a[3] = __builtin_fmaf(wgt, cvt16f_t<DT>((bf16_t)(m2.y >> 16)), a[3]);
-        }
+        f32x4_t ox[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] += __shfl_xor(a[e], 16, 64);
-            a[e] += __shfl_xor(a[e], 32, 64);
+        for (int dt = 0; dt < 4; ++dt) ox[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < ATX_NT / 2 + 1; ++kk) {
+            // hardware k index 8g + j <-> row 32kk + (j < 4 ? 4g + j : 16 + 4g + j - 4)
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+            pk.w[0] = pk.w[1] = pk.w[2] = pk.w[3] = 0u;
+            if (fr == 0) {
+                float lo[4], hi[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k0 = 32 * kk + 4 * g + j, k1 = k0 + 16;
+                    lo[j] = k0 < L ? wv[k0] : 0.f;
+                    hi[j] = k1 < L ? wv[k1] : 0.f;
+                }
+                pk.w[0] = pack2_t<DT>(lo[0], lo[1]); pk.w[1] = pack2_t<DT>(lo[2], lo[3]);
+                pk.w[2] = pack2_t<DT>(hi[0], hi[1]); pk.w[3] = pack2_t<DT>(hi[2], hi[3]);
+            }
+            const int r0 = 32 * kk + 4 * g + tq, r1 = r0 + 16 < ATB_ROWS ? r0 + 16 : ATB_ROWS - 1;      // (rows >= 129 carry weight 0)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int chunk = 2 * dt + (tp >> 1);
+                const bf16x4_t v0 = lds_tr16(img + d_off(r0, chunk) + ((tp & 1) << 3));
+                const bf16x4_t v1 = lds_tr16(img + d_off(r1, chunk) + ((tp & 1) << 3));
+                const bf16x8_t aT = (bf16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                ox[dt] = mfma16<DT>(aT, pk.v, ox[dt]);
+            }
         }
-        if (rq == 0) {
-            bf16_t* o = dqkv + ((size_t)s * L + XR) * D3 + wave * Dm + h * 64 + c4 * 4;
-            *(uint2*)o = make_uint2(pack2_t<DT>(a[0], a[1]), pack2_t<DT>(a[2], a[3]));
+        if (fr == 0) {      // lane (fr = 0, g) holds columns dt*16 + 4g .. +3 of the one live output column
+            bf16_t* orow = dqkv + ((size_t)s * L + XR) * D3 + wave * Dm + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *(uint2*)(orow + dt * 16) = make_uint2(pack2_t<DT>(ox[dt][0], ox[dt][1]), pack2_t<DT>(ox[dt][2], ox[dt][3]));
         }
     }
 
