@@ -33,13 +33,24 @@ PEAK_MFMA_TFLOPS = 2500.0   # MI355X dense bf16 / f16 MFMA peak (MI355X_MICROARC
 PROF_TN_GROUP = 101         # sig_prof_begin class id: gemm_tn_group_kernel (a transformer block's four weight gradients in one launch)
 # what tests/ assert for each operand type against the fp32 CPU oracle / the reference's fixtures (tests/test_model_gpu.py FEAT_TOL,
 # tests/test_train_gpu.py::test_full_train_step_vs_oracle); north_star asks 1e-3 on features / loss
-PARITY = {
-    "fp16": {"features_rel": "<= 1e-3 (measured 4.6e-4)", "loss_terms_rel": "<= 1e-3 (measured 3.5e-5)",
-             "per_parameter_grad_cos": ">= 0.9999 under the device's discrete decisions (measured 0.999998)", "meets_north_star_1e-3": True},
-    "bf16": {"features_rel": "<= 6e-3 (measured 3.8e-3; one GEMM's operand rounding alone is 2.35e-3)", "loss_terms_rel": "<= 2e-3 (measured 2e-4)",
-             "per_parameter_grad_cos": ">= 0.9995 under the device's discrete decisions (measured 0.99985)", "meets_north_star_1e-3": False},
+PARITY = {      # the BOUNDS the tests assert; what they last measured rides along as parity.measured (parity_object below)
+    "fp16": {"features_rel": "<= 1e-3", "loss_terms_rel": "<= 1e-3",
+             "per_parameter_grad_cos": ">= 0.9999 under the device's discrete decisions", "meets_north_star_1e-3": True},
+    "bf16": {"features_rel": "<= 6e-3 (one GEMM's operand rounding alone is 2.35e-3)", "loss_terms_rel": "<= 2e-3",
+             "per_parameter_grad_cos": ">= 0.9995 under the device's discrete decisions", "meets_north_star_1e-3": False},
     "sim_topk_indices": "bit-exact on tie-free rows (fixtures G2, G2b; B=64 sweep)",
 }
+
+
+def parity_object():
+    """`parity`: the bounds the GPU tests assert (PARITY above) with the values those tests last measured on an MI355X
+    (profiles/r04_parity_measured.json, written by tests/conftest.py::record_measure during `pytest -m gpu` and committed)."""
+    out = json.loads(json.dumps(PARITY))
+    path = os.path.join(ROOT, "profiles", "r04_parity_measured.json")
+    if os.path.exists(path):
+        out["measured"] = {"source": "profiles/r04_parity_measured.json (tests/test_model_gpu.py, tests/test_train_gpu.py on MI355X)",
+                           **json.load(open(path))}
+    return out
 
 
 def parse():
@@ -414,7 +425,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_MFMA_TFLOPS, 4), **traffic,
                      "launches": pn, "avg_us": round(pms / max(pn, 1) * 1e3, 2)},
-        "parity": PARITY,
+        "parity": parity_object(),
     }
     # the whole step against the MFMA peak (per GPU): what the kernels above add up to, HBM-bound kernels, launch gaps and the
     # optimizer included -- the figure the north star's ">= 40 % on the ViT block" is to be read against

@@ -52,6 +52,9 @@ def test_bench_default_is_the_train_step_with_the_json_contract():
     assert h["dtype"] == "fp16" and h["unit"] == "triplets/s" and 0.8 * d["value"] < h["value"] < 1.2 * d["value"]
     assert h["roofline"]["launches"] == 12 * 3 and h["loss_scale"]["init"] == 65536.0
     assert d["parity"]["fp16"]["meets_north_star_1e-3"] is True and d["parity"]["bf16"]["meets_north_star_1e-3"] is False
+    pm = d["parity"]["measured"]      # what the parity tests last measured on an MI355X (committed artifact), inside the stated bounds
+    assert pm["fp16_features_rel"] < 1e-3 and pm["bf16_features_rel"] < 6e-3 and pm["fp16_loss_terms_rel"] < 1e-3
+    assert pm["fp16_B64_per_parameter_grad_cos"] > 0.9999 and pm["bf16_B64_per_parameter_grad_cos"] > 0.9995
     f = d["fwd_sim"]
     assert f["workload"].startswith("configs[1]") and f["value"] > d["value"] and f["roofline"]["launches"] == 12 * 3
     c = d["cpu_baseline"]

@@ -77,6 +77,8 @@ def test_inference_features_vs_oracle(dev, tag, dtype):
     # 16-bit MFMA operands, fp32 accumulation / residual stream / LayerNorm / softmax (module docstring: which type
     # meets which bar)
     e_cls, e_pat = rel_err(c_h, cls), rel_err(p_h, patches)
+    from tests.conftest import record_measure
+    record_measure(f"{dtype}_features_rel", max(e_cls, e_pat, rel_err(feat[:, :1536], ref[:, :1536])))
     print(f"[{tag} {dtype}] rel err cls {e_cls:.2e} patches {e_pat:.2e} ori {rel_err(feat[:, :1536], ref[:, :1536]):.2e} "
           f"sim {rel_err(feat[:, 1536:], ref[:, 1536:]):.2e}")
     assert e_cls < tol and e_pat < tol

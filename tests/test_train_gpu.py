@@ -161,6 +161,9 @@ def test_full_train_step_vs_oracle(dev, golden, tag, dtype):
     np.testing.assert_allclose(out[-2].item(), float(g["gam"]), rtol=ltol)
     np.testing.assert_allclose(out[-1].item(), float(g["lam"]), rtol=ltol)
     np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=ltol)
+    from tests.conftest import record_measure
+    record_measure(f"{dtype}_loss_terms_rel", max(abs(out[-2].item() / float(g["gam"]) - 1), abs(out[-1].item() / float(g["lam"]) - 1),
+                                                   abs(loss.item() / float(g["loss"]) - 1)))
     hip_mask = torch.stack([model.SIM.token_selection.last_masks[m][..., 0] for m in O.MODALITIES]).cpu().numpy()
     agree = (hip_mask.astype(np.int8) == g["masks"]).mean()
     assert agree > 0.995, agree
@@ -230,6 +233,8 @@ def test_full_train_step_vs_oracle(dev, golden, tag, dtype):
     # CPU emulation of the 16-bit rounding points predicts (tests/probes/bf16_emulation.py: 0.99986), uniform over the blocks.
     worst, whole = compare(sdo, 0.9999 if dtype == "fp16" else 0.9995, 0.99999 if dtype == "fp16" else 0.9998, True)
     print(f"[train step {tag} {dtype}] under the device's decisions: worst parameter cos {worst:.6f}, whole gradient {whole:.7f}")
+    from tests.conftest import record_measure
+    record_measure(f"{dtype}_per_parameter_grad_cos", worst)
     if not flipped and not mining_flips:
         # the reference's per-parameter gradient norms (fixture G7) apply when no decision differs
         for k, rn in ref_norm.items():
@@ -321,6 +326,9 @@ def test_full_train_step_B64_vs_oracle(dev, dtype):
     assert whole > pw, whole
     print(f"[B=64 train step {dtype}] batch-hard choices flipped {mining_flips} of 256 (all near-ties < {tie:g}); under the device's "
           f"decisions: worst parameter cos {worst:.6f}, whole gradient {whole:.7f}")
+    from tests.conftest import record_measure
+    record_measure(f"{dtype}_B64_per_parameter_grad_cos", worst)
+    record_measure(f"{dtype}_B64_whole_grad_cos", whole)
 
 
 def test_fused_adam_matches_torch(dev):
