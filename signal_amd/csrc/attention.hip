@@ -508,12 +508,13 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------------------
 // Backward for L = 16 * 8 + 1 (every shipped geometry: 128 patches + the class token).  With nine 16-row tiles the
 // ninth is 94 % padding: 17 of the 81 (query tile, key tile) pairs are almost empty, and nine tasks per pass on three
-// waves leave the block's time at three tasks per pass.  Here the first 128 rows are EIGHT clean tiles on FOUR waves (two
-// tasks per wave and pass) and row 128 -- `x` below -- is handled beside the matrix cores:
-//   column x of S / dP (every query against key x) and row x (query x against every key): 4 x 129 dot products of 64 on
-//   the VALU, one matrix per wave; from them P[:,x], dS[:,x], P[x,:], dS[x,:];
-//   dQ[x] = sum_j dS[x,j] K[j],  dK[x] = sum_i dS[i,x] Q[i],  dV[x] = sum_i P[i,x] dO[i]: three 64-wide reductions over
-//   129 rows, one per wave;
+// waves leave the block's time at three tasks per pass.  Here the first 128 rows are EIGHT clean tiles -- one per wave on
+// eight waves (PAIR = 1, the default: the arithmetic phase of a block, which bounds the kernel, then has two waves per SIMD)
+// or two per wave on four (PAIR = 2) -- and row 128, `x` below, is handled beside them:
+//   column x of S / dP (every query against key x) and row x (query x against every key): 4 x 129 dot products of 64, one
+//   per thread, as packed two-element dot products (v_dot2c); from them P[:,x], dS[:,x], P[x,:], dS[x,:];
+//   dQ[x] = sum_j dS[x,j] K[j],  dK[x] = sum_i dS[i,x] Q[i],  dV[x] = sum_i P[i,x] dO[i]: one wave each, on the matrix cores
+//   (the transposed image fragments of the passes against a B operand whose only non-zero column is the weight vector);
 //   the rank-1 terms dQ[i] += dS[i,x] k_x, dK[j] += dS[x,j] q_x, dV[j] += P[x,j] dO_x are added to the MFMA accumulators of
 //   pass A / pass B just before they are stored (16 FMAs per lane and tile).
 // Everything else (dual-use LDS images, passes A and B, in-register dS) is the kernel above with 8 tiles.
