@@ -184,7 +184,7 @@ def step_mfma_flops(B, train=True, L=129, D=768, depth=12, heads=12, patches=128
     return depth * (3 * gemm + 3.5 * attn) + 2 * embed
 
 
-def live_tn_plan(M):
+def live_tn_plan(M, cus=256):
     """The grouped weight gradient's work plan for this run's shapes and free CUs, from the library's own planner
     (sig_debug_tn_plan): {balanced, nsplit, per, short_group, n_long, n_short_wg, workgroups, colsum_inside}."""
     from signal_amd import _lib
@@ -192,7 +192,7 @@ def live_tn_plan(M):
     mp = (M + 127) // 128 * 128
     out8 = (ctypes.c_int * 8)()
     # a ViT-B/16 block: 27 + 9 + 36 + 36 = 108 output tiles of 256x256, Mp / 64 K-steps, 36 column-sum units (in_proj bias)
-    if lib.sig_debug_tn_plan(108, mp // 64, 256, 36, out8) != 0:
+    if lib.sig_debug_tn_plan(108, mp // 64, cus, 36, out8) != 0:      # (cus: 256 minus what the trainer reserves for RCCL at N > 1)
         return None
     return list(out8)
 
@@ -325,7 +325,8 @@ def main():
     el, (pms, pn, pfl) = timed(step, args.steps, args.warmup, prof)
     loss_scale_desc = ts.scaler.describe() if ts is not None and getattr(ts, "scaler", None) is not None else None
     ach = pfl / (pms * 1e-3) / 1e12 if pn else 0.0
-    traffic = committed_traffic(kkey, pms / max(pn, 1) * 1e3, live_tn_plan(M) if kkey == "gemm_tn_group_kernel" else None)
+    free_cus = 256 - (getattr(ts, "reserved_cus", 0) if ts is not None else 0)      # the backward's GEMMs are planned for these
+    traffic = committed_traffic(kkey, pms / max(pn, 1) * 1e3, live_tn_plan(M, free_cus) if kkey == "gemm_tn_group_kernel" else None)
 
     fwd = None
     if args.workload == "train" and not args.no_fwd_sim:
