@@ -171,6 +171,16 @@ def test_gemm_nt_persistent_kernel(dev, dt16, m, n, k):
     for epi, r in want.items():
         assert rel_err(got[(3, epi)][:m].float(), r) < 4e-3 * T, epi
         assert torch.equal(got[(3, epi)], got[(0, epi)]), f"persistent and per-tile kernels differ (epilogue {epi})"
+    # with CUs left to RCCL (the data-parallel backward: 240 workgroups walk the tiles instead of 256) the same bits
+    prev_r, prev_p = lib.sig_tune_reserved_cus(16), lib.sig_tune_nt_persist(1)
+    try:
+        for epi in (ops.BIAS_BF16,) + ((ops.DGELU_BF16,) if uu is not None else ()):
+            ob = torch.zeros(ops.pad_rows(m), n, device=dev, dtype=dt16)
+            ops.gemm_nt(ap, w, m, epi, ob, **(dict(bias=None, aux=padded(uu, ops)) if epi == ops.DGELU_BF16 else dict(bias=bias)))
+            assert torch.equal(ob, got[(3, epi)]), f"persistent kernel on 240 CUs differs (epilogue {epi})"
+    finally:
+        lib.sig_tune_nt_persist(prev_p)
+        lib.sig_tune_reserved_cus(prev_r)
     sg = torch.sigmoid(1.702 * pre)
     assert torch.equal(saved[3][0], got[(3, ops.BIAS_GELU_BF16)]) and torch.equal(saved[3][0], saved[0][0])
     assert torch.equal(saved[3][1], saved[0][1]), "saved QuickGELU' differs between the persistent and the per-tile kernel"
