@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("SIGNAL_HIP_LIB") or os.path.join(_HERE, "lib", "libsi
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
-_TUNING_ONLY = {"sig_tune_gemm_tile", "sig_tune_nt_persist", "sig_tune_ln_defer", "sig_ln_flush", "sig_tune_attn_bwd_waves", "sig_tune_attn_fwd_waves", "sig_tune_reserved_cus", "sig_tune_tn_path", "sig_debug_tn_plan"}
+_TUNING_ONLY = {"sig_tune_gemm_tile", "sig_tune_nt_persist", "sig_tune_ln_defer", "sig_ln_flush", "sig_tune_tn_overwrite", "sig_zero_ranges", "sig_tune_attn_bwd_waves", "sig_tune_attn_fwd_waves", "sig_tune_reserved_cus", "sig_tune_tn_path", "sig_debug_tn_plan"}
 
 # name -> argtypes; mirrors include/signal_hip.h one to one (tests check the export list against the header)
 SIGNATURES = {
@@ -20,9 +20,11 @@ SIGNATURES = {
     "sig_tune_gemm_tile": [_i],
     "sig_tune_nt_persist": [_i],
     "sig_tune_ln_defer": [_i],
+    "sig_tune_tn_overwrite": [_i],
     "sig_tune_attn_bwd_waves": [_i],
     "sig_tune_attn_fwd_waves": [_i],
     "sig_ln_flush": [_vp],
+    "sig_zero_ranges": [_vp, _vp, _vp, _i, _i, _vp],
     "sig_tune_reserved_cus": [_i],
     "sig_tune_tn_path": [_i],
     "sig_debug_tn_plan": [_i, _i, _i, _i, _vp],

@@ -29,6 +29,7 @@ int sig_prof_begin(int epilogue, int N, int K, int max_launches) { return sig_pr
 int sig_tune_gemm_tile(int tile) { return sig_tune_gemm_tile_impl(tile); }
 int sig_tune_nt_persist(int on) { return sig_tune_nt_persist_impl(on); }
 int sig_tune_ln_defer(int on) { return sig_tune_ln_defer_impl(on); }
+int sig_tune_tn_overwrite(int on) { return sig_tune_tn_overwrite_impl(on); }
 int sig_tune_attn_bwd_waves(int waves) { return sig_tune_attn_bwd_waves_impl(waves); }
 int sig_tune_attn_fwd_waves(int waves) { return sig_tune_attn_fwd_waves_impl(waves); }
 int sig_ln_flush(void* stream) { return sig_ln_flush_impl((hipStream_t)stream); }
@@ -135,6 +136,9 @@ int sig_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p16, i
                   const float* scale_state, size_t n, void* stream) {
     return sig_launch_adam(p, g, m, v, p16, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, step, grad_scale, scale_state, dtype, n,
                            (hipStream_t)stream);
+}
+int sig_zero_ranges(float* base, const int64_t* table, const int* chunk_start, int n, int total_chunks, void* stream) {
+    return sig_launch_zero_ranges(base, (const long long*)table, chunk_start, n, total_chunks, (hipStream_t)stream);
 }
 int sig_grad_check(const float* g, size_t n, float* scale_state, void* stream) {
     return sig_launch_grad_check(g, n, scale_state, (hipStream_t)stream);

@@ -32,6 +32,7 @@
 // counted lgkmcnt waits, one barrier per K-step.
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -49,6 +50,7 @@ struct SigTnGroup {
     int balanced, short_group, n_long, n_short_wg;
     float* ws;                        // [nsplit * tiles] slots of 65536 floats, slot = chunk * tiles + tile
     int* cnt;                         // [tiles] arrival counters, zero between launches; nullptr = the two-kernel form (A/B runs)
+    int overwrite;                    // dW = sum of the partials instead of dW += (sig_tune_tn_overwrite: the caller never zeroed dW)
 };
 
 typedef uint32_t u32x4_tn __attribute__((ext_vector_type(4)));
@@ -444,12 +446,33 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(SigTnGroup p) {
     const int j = (tl % tj) * 256 + (wave & 3) * 64 + c4;
     float* o = job.out + (size_t)i * job.ldo + j;
     const f32x4_t add = *(const f32x4_t*)&tile[row][c4];
-    if ((job.ldo & 3) == 0) {
+    if (p.overwrite) {      // (uniform) the first and only writer of dW this step: no read of stale contents
+        if ((job.ldo & 3) == 0) {
+            *(f32x4_t*)o = add;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = add[e];
+        }
+    } else if ((job.ldo & 3) == 0) {
         *(f32x4_t*)o = *(const f32x4_t*)o + add;
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += add[e];
     }
+}
+
+// dW = ... instead of dW += ... for every job of a grouped launch (sig_tune_tn_overwrite): a caller that owns a whole backward pass
+// and writes every weight gradient exactly once per step need not zero them first.  The paths that accumulate by construction
+// (in-launch reduce, per-weight fallbacks with atomics or their own reduce) zero the output themselves first.
+static std::atomic<int> g_tn_overwrite{0};
+int sig_tune_tn_overwrite_impl(int on) { return g_tn_overwrite.exchange(on ? 1 : 0); }
+static int tn_zero_outputs(const SigTnJob* jobs, int njobs, hipStream_t st) {
+    for (int k = 0; k < njobs; ++k)
+        if (hipMemset2DAsync(jobs[k].out, (size_t)jobs[k].ldo * sizeof(float), 0, (size_t)jobs[k].J * sizeof(float), jobs[k].I, st) != hipSuccess) {
+            sig_set_error("gemm_tn_grouped: hipMemset2DAsync failed");
+            return 2;
+        }
+    return 0;
 }
 
 // can the grouped kernel take these jobs?  (every output a multiple of 256 x 256)
@@ -598,6 +621,10 @@ static int launch_group(const SigTnJob* jobs, int njobs, int Mr, int grid, int t
     if (sig_ceil_div(g.nsplit * tiles, g.grid) > 64) inkernel = 0;
     g.cnt = (inkernel && ws_bytes < 0x7fffffffull) ? (int*)sig_stream_scratch(st, 4096, 2) : nullptr;     // (new scratch is zero-filled)
     SIG_CHECK_ARG(tiles <= 1024, "gemm_tn_grouped: %d output tiles (at most 1024 arrival counters)", tiles);
+    g.overwrite = g_tn_overwrite.load();
+    if (g.overwrite && g.cnt) {                 // the in-launch reduce read-modify-writes dW: start it from zero
+        if (int rc = tn_zero_outputs(jobs, njobs, st)) return rc;
+    }
     const bool timed = sig_prof_tn_start(st, SIG_PROF_TN_GROUP, 0, 0);
     hipLaunchKernelGGL(gemm_tn_group_kernel<DT>, dim3(g.grid), dim3(512), LDS_BYTES, st, g);
     SIG_CHECK_LAUNCH("gemm_tn_group");
@@ -661,7 +688,10 @@ int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, 
         // rc == -1: no workspace for the partial tiles (hipMalloc failed, or the scratch table is full): one launch per weight
         // below, which itself falls back to f32 atomics without a workspace
     }
-    // shapes the grouped kernel does not take (outputs that are not multiples of 256): one launch per weight
+    // shapes the grouped kernel does not take (outputs that are not multiples of 256): one launch per weight (they accumulate)
+    if (g_tn_overwrite.load()) {
+        if (int rc = tn_zero_outputs(jobs, njobs, st)) return rc;
+    }
     for (int k = 0; k < njobs; ++k) {
         SigGemmTN p{};
         p.P = jobs[k].P; p.Q = jobs[k].Q; p.ldp = jobs[k].ldp; p.ldq = jobs[k].ldq; p.Mr = Mr; p.I = jobs[k].I; p.J = jobs[k].J;

@@ -84,6 +84,26 @@ int sig_launch_grad_check(const float* g, size_t n, float* state, hipStream_t st
     return 0;
 }
 
+// Zero a list of ranges of one buffer in ONE launch: table[k] = {offset, length} in floats, chunk_start[k] = first block of range k
+// (4096 floats per block), chunk_start[n] = grid.  The training engine zeroes the gradients that ACCUMULATE during a step this way
+// and leaves out the transformer blocks' weight gradients, which its backward overwrites (sig_tune_tn_overwrite).
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const long long* __restrict__ table,
+                                                          const int* __restrict__ chunk_start, int n) {
+    const int b = blockIdx.x;
+    int k = 0;
+    while (k + 1 < n && chunk_start[k + 1] <= b) ++k;      // (uniform; a few dozen ranges)
+    const long long off = table[2 * k], len = table[2 * k + 1], c0 = (long long)(b - chunk_start[k]) * 4096;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (c0 + i < len) base[off + c0 + i] = 0.f;
+}
+int sig_launch_zero_ranges(float* base, const long long* table, const int* chunk_start, int n, int total_chunks, hipStream_t st) {
+    SIG_CHECK_ARG(base && table && chunk_start && n > 0 && total_chunks > 0, "zero_ranges: bad arguments");
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(total_chunks), dim3(256), 0, st, base, table, chunk_start, n);
+    SIG_CHECK_LAUNCH("zero_ranges");
+    return 0;
+}
+
 __global__ void loss_scale_update_kernel(float* __restrict__ state, float growth, float backoff, int interval) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float scale = state[LS_SCALE], track = state[LS_TRACK];

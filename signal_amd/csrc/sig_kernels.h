@@ -73,6 +73,7 @@ struct SigTnJob {
 };
 int sig_launch_gemm_tn_grouped(const SigTnJob* jobs, int njobs, int Mr, int dt, hipStream_t st);
 int sig_debug_tn_plan_impl(int tiles, int ks, int grid, int cs_units, int* out);
+int sig_tune_tn_overwrite_impl(int on);                       // grouped weight gradients overwrite dW instead of adding to it
 int sig_free_cus();                                            // 256 minus the CUs reserved for RCCL (sig_tune_reserved_cus)
 #ifndef SIG_PROF_TN_GROUP
 #define SIG_PROF_TN_GROUP 101   // sig_prof_begin class: gemm_tn_group_kernel launches (a block's four weight gradients)
@@ -146,6 +147,7 @@ int sig_launch_adam(float* p, const float* g, float* m, float* v, bf16_t* p_bf16
                     size_t n, hipStream_t st);
 // fp16 loss scaling (engine/processor.py:119,259-261): state = [scale, 1/scale, found_inf, growth_tracker, applied_steps]
 int sig_launch_grad_check(const float* g, size_t n, float* state, hipStream_t st);
+int sig_launch_zero_ranges(float* base, const long long* table, const int* chunk_start, int n, int total_chunks, hipStream_t st);
 int sig_launch_loss_scale_update(float* state, float growth, float backoff, int interval, hipStream_t st);
 
 // ---- ReID head (reid.hip) ----------------------------------------------------------------------------------

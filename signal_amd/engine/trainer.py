@@ -67,6 +67,7 @@ class TrainStep:
         # parameters that cannot receive a gradient in this stage keep .grad = None, exactly what autograd leaves the
         # reference with: torch optimizers skip them (no weight decay on W_q/W_k, no moment updates)
         hip.enable_direct_grads(skip=self.inactive)
+        hip.enable_wgrad_overwrite()
         optimizer = optimizer or make_optimizer(cfg, model, None)[0]
         if not isinstance(optimizer, FusedAdam) and FusedAdam.can_adopt(optimizer):
             # the reference's train.py builds the optimizer while the model is still on the CPU; keep its param_groups
@@ -124,7 +125,7 @@ class TrainStep:
 
     def step(self, img, target, target_cam, target_view=None):
         hip = self.model.hip
-        hip.flat.grad.zero_()
+        hip.zero_grads()                     # (the blocks' weight gradients are overwritten by the backward, not zeroed: hip.wgrad_overwrite)
         hip.arena_begin(hip.flat.device)     # ONE fill for every small zero-initialised buffer of the step's head stages
         try:
             return self._step(hip, img, target, target_cam, target_view)

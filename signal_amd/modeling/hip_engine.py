@@ -181,6 +181,47 @@ class HipPath:
         for n, p in self.flat.byname.items():
             p.grad = None if (skip(n) or not p.requires_grad) else self.flat.view(self.flat.grad, n)
 
+    # Training-engine mode on top of direct_grads: the transformer blocks' weight gradients (340 of the 345 MB of flat.grad) are
+    # written exactly once per step, by the grouped weight-gradient launch of sig_block_bwd.  With sig_tune_tn_overwrite around the
+    # backward that launch WRITES them (no read of the old contents), and the top of the step zeroes only everything else --
+    # the gradients that really accumulate (biases, LayerNorm, embeddings, heads) -- with one sig_zero_ranges launch.
+    wgrad_overwrite = False
+    _zero_tab = None
+
+    def enable_wgrad_overwrite(self) -> bool:
+        import os
+        lib = _lib.load()
+        if not (self.direct_grads and hasattr(lib, "sig_tune_tn_overwrite") and hasattr(lib, "sig_zero_ranges")):
+            return False
+        if os.environ.get("SIGNAL_WGRAD_OVERWRITE", "1") == "0":       # A/B runs: the one-memset form
+            return False
+        fl = self.flat
+        taken = sorted((fl.offsets[n], fl.byname[n].numel()) for n in self.block_weight_names)
+        ranges, pos = [], 0
+        for o, n in taken:            # (the alignment padding behind a tensor stays in the zeroed complement)
+            if o > pos:
+                ranges.append((pos, o - pos))
+            pos = o + n
+        if pos < fl.total:
+            ranges.append((pos, fl.total - pos))
+        starts, tot = [], 0
+        for _, ln in ranges:
+            starts.append(tot)
+            tot += (ln + 4095) // 4096
+        starts.append(tot)
+        self._zero_tab = (torch.tensor(ranges, dtype=torch.int64, device=fl.device), torch.tensor(starts, dtype=torch.int32, device=fl.device),
+                          len(ranges), tot)
+        self.wgrad_overwrite = True
+        return True
+
+    def zero_grads(self):
+        """Top of a training step: every gradient that accumulates during the step starts from zero."""
+        if self.wgrad_overwrite:
+            table, starts, n, tot = self._zero_tab
+            _lib.call("sig_zero_ranges", self.flat.grad.data_ptr(), table.data_ptr(), starts.data_ptr(), n, tot, _stream())
+        else:
+            self.flat.grad.zero_()
+
     def after_fused_step(self):
         """The fused optimizer already refreshed flat.op16; redo the transposed copies and mark versions."""
         self._pack(cast=False)
@@ -240,6 +281,7 @@ class HipPath:
         self.embed_param_names = [base + "conv1.weight", base + "class_embedding", base + "positional_embedding",
                                   base + "ln_pre.weight", base + "ln_pre.bias"] + ([cv] if cv else [])
         self.block_p, self.block_g = [], []
+        self.block_weight_names = []        # the four big matrices of every block: what the grouped weight-gradient launch writes
         for i in range(self.layers):
             p = f"{base}transformer.resblocks.{i}."
             names = dict(w_in=p + "attn.in_proj_weight", w_out=p + "attn.out_proj.weight", w_fc=p + "mlp.c_fc.weight",
@@ -247,6 +289,7 @@ class HipPath:
                          b_fc=p + "mlp.c_fc.bias", b_proj=p + "mlp.c_proj.bias", ln1_w=p + "ln_1.weight",
                          ln1_b=p + "ln_1.bias", ln2_w=p + "ln_2.weight", ln2_b=p + "ln_2.bias")
             shapes = dict(w_in=(3 * D, D), w_out=(D, D), w_fc=(Fd, D), w_proj=(D, Fd))
+            self.block_weight_names += [names[k] for k in shapes]
             kw = {}
             for k, n in names.items():
                 kw[k] = self._pk(n) if k.startswith("w_") else self._p(n)
@@ -434,9 +477,12 @@ class HipPath:
         lib = _lib.load()
         chain = self.on_block_grads_ready is None and self.on_head_grads_ready is None and hasattr(lib, "sig_tune_ln_defer")
         prev_defer = lib.sig_tune_ln_defer(1) if chain else 0
+        prev_ow = lib.sig_tune_tn_overwrite(1) if self.wgrad_overwrite else 0
         try:
             self._vit_backward_stages(ws, st, d)
         finally:
+            if self.wgrad_overwrite:
+                lib.sig_tune_tn_overwrite(prev_ow)
             if chain:
                 lib.sig_tune_ln_defer(prev_defer)
                 _lib.call("sig_ln_flush", st)

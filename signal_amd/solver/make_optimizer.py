@@ -110,7 +110,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.hip.after_fused_step()
 
     def zero_grad(self, set_to_none: bool = False):
-        self.hip.flat.grad.zero_()
+        self.hip.zero_grads()
 
 
 def make_optimizer(cfg, model, center_criterion=None):

@@ -574,6 +574,49 @@ def test_backward_is_reproducible_run_to_run(dev):
     assert err < 1e-6
 
 
+@pytest.mark.parametrize("B", [64, 8])
+def test_overwritten_block_weight_gradients_equal_zeroed_then_accumulated(dev, B, monkeypatch):
+    """TrainStep does not zero the transformer blocks' weight gradients (340 of flat.grad's 345 MB): the grouped weight-gradient
+    launch of the backward overwrites them (sig_tune_tn_overwrite), one sig_zero_ranges launch zeroes everything else.  Three
+    steps on three different batches (every learning rate 0: the parameters stay put, so every step's gradient is a function of its
+    batch alone -- with moving parameters the f32-atomics noise of two runs is amplified by Adam's sign-like first steps) must give the same losses, bit for bit, and the same final gradient -- to the 1e-6 that two runs of one engine differ by,
+    some bias / LayerNorm gradients being summed with f32 atomics -- as the engine that zeroes the whole buffer and accumulates
+    (SIGNAL_WGRAD_OVERWRITE=0): a stale or double-counted gradient would be off by a factor.  The un-zeroed part is poisoned with
+    NaN first.  B = 64 runs the grouped kernel + reduce, B = 8 the per-weight fallback (which zeroes its outputs itself)."""
+    from signal_amd.engine.trainer import TrainStep
+    from signal_amd.modeling import make_frame
+    ocfg = O.rgbnt201_config() if B == 64 else O.rgbnt201_config(num_instance=4)      # (at least two identities per batch)
+    sd = O.init_state_dict(ocfg, seed=31, head_scale=30.0)
+    batches = []
+    for k in range(3):
+        img, vid, cam = O.synthetic_batch(ocfg, B, seed=90 + k)
+        batches.append(({m: v.to(dev) for m, v in img.items()}, vid.to(dev), cam.to(dev)))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SIGNAL_WGRAD_OVERWRITE", mode)
+        cfg = make_cfg(ocfg, "bf16")
+        cfg.SOLVER.OPTIMIZER_NAME, cfg.SOLVER.BASE_LR = "Adam", 0.0
+        model = make_frame(cfg, ocfg.num_classes, ocfg.camera_num, 0)
+        model.load_state_dict(sd, strict=False)
+        model.to(dev)
+        ts = TrainStep(cfg, model, num_classes=ocfg.num_classes)
+        for grp in ts.optimizer.param_groups:       # (BASE_LR = 0 leaves the backbone its fixed 5e-6, solver/make_optimizer.py:20)
+            grp["lr"], grp["weight_decay"] = 0.0, 0.0
+        assert model.hip.wgrad_overwrite == (mode == "1")
+        if mode == "1":       # poison what the engine no longer zeroes: the backward must overwrite every element of it
+            for n in model.hip.block_weight_names:
+                model.hip._g(n).fill_(float("nan"))
+        losses = [ts.step(*b).item() for b in batches]
+        torch.cuda.synchronize()
+        out[mode] = (losses, model.hip.flat.grad.clone(), model.hip.flat.data.clone())
+        del ts, model
+    assert out["1"][0] == out["0"][0], (out["1"][0], out["0"][0])
+    assert len(set(out["1"][0])) == 3                                   # (three different batches)
+    assert bool(torch.isfinite(out["1"][1]).all())
+    assert rel_err(out["1"][1], out["0"][1]) < 1e-6, "gradients differ between the overwrite and the zero-and-accumulate engine"
+    assert torch.equal(out["1"][2], out["0"][2])                        # (learning rate 0)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_benched_batch_train_step_big_tiles_vs_small_tiles(dev, dtype):
     """The train step AT THE BENCHED SIZE (RGBNT201, both operand types, B = 64: 320x256 / 256x256 NT tiles with their training epilogues --
