@@ -472,11 +472,13 @@ class HipPath:
         gradient into flat.grad."""
         st, d = _stream(), ref(ws["dims"])
         # The 25 LayerNorm backwards of this pass chain their column reduces (each launch adds up the previous one's partial rows
-        # in its first workgroups; one flush at the end) instead of 25 small reduce launches -- unless a data-parallel reducer is
-        # hooked in: it sends a block's bucket as soon as that block's backward is enqueued, so every gradient must be final then.
+        # in its last workgroups; one flush at the end) instead of 25 small reduce launches.  With a data-parallel reducer hooked
+        # in, a stage's gradients are final one LayerNorm launch later than its backward is enqueued, so its hook fires after the
+        # NEXT stage's backward (see _vit_backward_stages).
         lib = _lib.load()
-        chain = self.on_block_grads_ready is None and self.on_head_grads_ready is None and hasattr(lib, "sig_tune_ln_defer")
+        chain = hasattr(lib, "sig_tune_ln_defer")
         prev_defer = lib.sig_tune_ln_defer(1) if chain else 0
+        self._ln_chained = chain
         prev_ow = lib.sig_tune_tn_overwrite(1) if self.wgrad_overwrite else 0
         try:
             self._vit_backward_stages(ws, st, d)
@@ -491,15 +493,29 @@ class HipPath:
         _lib.call("sig_head_bwd", d, ref(self.head_p), ref(ws["head_a"]), ref(self.head_g), ws["dtokens"].data_ptr(),
                   ws["dtok_b"].data_ptr(), ws["dh"].data_ptr(), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(),
                   self.b_proj_grad[self.layers - 1].data_ptr(), st)
-        if self.on_head_grads_ready is not None:     # every head-side gradient (heads ran before this backward) is final now
+        # Hooks of the data-parallel reducer.  With the chained LayerNorm reduce a stage's last LayerNorm launch leaves its column
+        # sums (ln weights / biases, a c_proj bias gradient) parked as partial rows; the FIRST LayerNorm launch of the next stage
+        # adds them up.  So "stage s is final" holds once the stage after it is enqueued: the head's hook fires after block
+        # L-1's backward, block i's after block i-1's, block 0's after an explicit flush.  Without chaining: right away.
+        chained = getattr(self, "_ln_chained", False)
+        if self.on_head_grads_ready is not None and not chained:     # every head-side gradient (heads ran before this backward) is final now
             self.on_head_grads_ready()
         for i in reversed(range(self.layers)):
             below = self.b_proj_grad[i - 1].data_ptr() if i > 0 else None   # column sums of dx_in = block i-1's c_proj bias grad
             _lib.call("sig_block_bwd", d, ref(self.block_p[i]), ref(ws["block_a"][i]), ref(self.block_g[i]),
                       ref(ws["scratch"]), ws["dx"].data_ptr(), ws["dx_b"].data_ptr(), ws["dx"].data_ptr(),
                       ws["dx_b"].data_ptr(), below, 1, st)
-            if self.on_block_grads_ready is not None:
+            if chained:
+                if i == self.layers - 1:
+                    if self.on_head_grads_ready is not None:
+                        self.on_head_grads_ready()
+                elif self.on_block_grads_ready is not None:
+                    self.on_block_grads_ready(i + 1)
+            elif self.on_block_grads_ready is not None:
                 self.on_block_grads_ready(i)
+        if chained and self.on_block_grads_ready is not None:
+            _lib.call("sig_ln_flush", st)            # block 0's last LayerNorm launch has no successor yet
+            self.on_block_grads_ready(0)
         cam = ws["cam"]
         _lib.call("sig_embed_bwd", d, ref(self.embed_p), ref(ws["embed_a"]), ref(self.embed_g), ws["dx"].data_ptr(),
                   ws["dpre"].data_ptr(), ws["dtok_e"].data_ptr(), None if cam is None else cam.data_ptr(), self.patch, st)
